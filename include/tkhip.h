@@ -1,0 +1,300 @@
+/*
+ * tkhip.h — C ABI of the MI355X (gfx950) SPPM backend.
+ *
+ * Plain C types only: POD structs, pointers and sizes.  No exception crosses
+ * this boundary; every function returns 0 on success and a negative TKHIP_E_*
+ * code on failure, with a human-readable reason available from
+ * tkhip_last_error().  Citations "file:line" refer to the upstream CPU
+ * renderer (tohkachan/PathTracer, src/...) whose interface each entry point
+ * replaces.
+ *
+ * Pointer conventions
+ *   "host"   : ordinary process memory, read or written synchronously.
+ *   "device" : memory of the context's GPU (hipMalloc / torch CUDA tensor
+ *              data_ptr).  Calls that take device pointers enqueue work on the
+ *              context's stream and synchronise before returning unless the
+ *              function's comment says otherwise.
+ */
+#ifndef TKHIP_H
+#define TKHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ errors */
+#define TKHIP_OK 0
+#define TKHIP_E_ARG (-1)     /* bad argument (null pointer, size out of range) */
+#define TKHIP_E_STATE (-2)   /* call order violated (e.g. no scene set)        */
+#define TKHIP_E_HIP (-3)     /* a HIP runtime call or kernel launch failed     */
+#define TKHIP_E_NOMEM (-4)   /* allocation failed                              */
+#define TKHIP_E_LIMIT (-5)   /* size beyond a documented limit                 */
+
+/* Material type flags: src/core/Material.hpp:14 */
+#define TK_DIFFUSE 0x1
+#define TK_MIRROR 0x2
+#define TK_GLASS 0x4
+
+/* Largest kNN sample count a photon map accepts (gsample/csample). */
+#define TKHIP_MAX_K 448
+
+/* ------------------------------------------------------------- scene PODs */
+
+/* One triangle in world space (vertices already transformed):
+ * src/Triangle.hpp:12-25 (v0,v1,v2; e1,e2,normal,area are derived). */
+typedef struct TkTriangle {
+    float v0[3];
+    float v1[3];
+    float v2[3];
+} TkTriangle;
+
+/* src/Sphere.hpp:15-16 */
+typedef struct TkSphere {
+    float center[3];
+    float radius;
+} TkSphere;
+
+/* src/core/Material.hpp:106-146.  type is one TK_* flag.
+ * diffuse: R.  mirror: R.  glass: R, T, etaA (outside, 1.0), etaB (inside). */
+typedef struct TkMaterial {
+    int32_t type;
+    float R[3];
+    float T[3];
+    float etaA;
+    float etaB;
+} TkMaterial;
+
+/* src/AreaLight.hpp:13-37: an area light bound to one mesh object. */
+typedef struct TkLight {
+    float Le[3];
+    int32_t two_sided; /* the loader always passes 0: src/TkLoader.cpp:336 */
+    int32_t object;    /* index of the mesh object that emits */
+} TkLight;
+
+/* src/core/Object.hpp: shape + material + optional light.
+ * kind 0: mesh  = triangles [first, first+count) of the triangle array.
+ * kind 1: sphere = spheres  [first, first+1)     of the sphere array. */
+typedef struct TkObject {
+    int32_t kind;
+    int32_t first;
+    int32_t count;
+    int32_t material;
+    int32_t light; /* -1 if the object does not emit */
+} TkObject;
+
+/* src/TkConfigure.h:29-37.  radius2 is used directly as r^2
+ * (src/tracer/TkSppmTracer.cpp:14, :395). */
+typedef struct TkSppmParam {
+    int32_t numRecurse;
+    int32_t globalSize;
+    int32_t globalSample;
+    int32_t causticSize;
+    int32_t causticSample;
+    float radius2;
+} TkSppmParam;
+
+/* src/tracer/TkSppmTracer.h:9-19, same field order, 13 floats = 52 bytes. */
+typedef struct TkSPPMPixel {
+    float Ld[3];
+    float causticFlux[3];
+    float globalFlux[3];
+    float causticPhotons;
+    float globalPhotons;
+    float causticRadius2;
+    float globalRadius2;
+} TkSPPMPixel;
+
+/* Counters of one iteration (or of one pass when the passes are called
+ * separately); also the per-phase device time in milliseconds. */
+typedef struct TkIterStats {
+    int64_t global_paths;     /* light paths traced for the global map (this call)  */
+    int64_t caustic_paths;    /* light paths traced for the caustic map (this call) */
+    int64_t global_stored;    /* photons in the global map                          */
+    int64_t caustic_stored;   /* photons in the caustic map                         */
+    int64_t shoot_global;     /* cumulative shootGlobalPhotons (TkSppmTracer.h:31)  */
+    int64_t shoot_caustic;    /* cumulative shootCausticPhotons (TkSppmTracer.h:32) */
+    int64_t rays;             /* closest-hit + shadow queries (this call)           */
+    int64_t gathers_global;   /* radiance_estimate calls on the global map          */
+    int64_t gathers_caustic;  /* radiance_estimate calls on the caustic map         */
+    int64_t gather_photons;   /* sum of photons found over all gathers              */
+    float ms_photon;          /* photon passes + compaction                         */
+    float ms_build;           /* both KD-tree builds                                */
+    float ms_camera;          /* camera paths incl. NEE, without gathers            */
+    float ms_gather;          /* all gather kernels incl. query sort + pixel update */
+    float ms_gather_kernel;   /* the dominant (grouped) gather kernel only          */
+    float ms_total;
+} TkIterStats;
+
+typedef struct tkhip_ctx tkhip_ctx;
+typedef struct tkhip_map tkhip_map;
+
+/* --------------------------------------------------------------- lifecycle */
+
+/* Thread-local text of the last failure in this thread. */
+const char* tkhip_last_error(void);
+
+/* Library build tag (used by loaders to check that the right .so is loaded). */
+const char* tkhip_version(void);
+
+/* One context per GPU.  Owns a stream and every device buffer created through
+ * it.  Replaces the tracer object construction in parse_tracer,
+ * src/TkLoader.cpp:228-251. */
+int tkhip_create(int device, tkhip_ctx** out);
+void tkhip_destroy(tkhip_ctx* ctx);
+
+/* --------------------------------------------------------- scene and camera */
+
+/* Flattens the scene into one linear BVH over every triangle and sphere and
+ * uploads it.  Replaces Scene::buildBVH + the per-mesh BVHAccel
+ * (src/core/Scene.cpp:18-20, src/Triangle.cpp:179, src/BVH.cpp:62-243) and
+ * RayTracer::setScene (src/core/TkRayTracer.cpp:36-41).  Host pointers. */
+int tkhip_set_scene(tkhip_ctx* ctx,
+                    const TkObject* objects, int n_objects,
+                    const TkTriangle* tris, int n_tris,
+                    const TkSphere* spheres, int n_spheres,
+                    const TkMaterial* materials, int n_materials,
+                    const TkLight* lights, int n_lights);
+
+/* Row-major 4x4 matrices as the reference stores them (src/Matrix4.h:11-15):
+ * c2w = CameraInfo::c2w after rotate(0,0)+setTranslation (src/main.cpp:39-40),
+ * raster2cam = Camera::rasterToCamera (src/core/camera.cpp:15-20).
+ * Replaces RayTracer::setCamera (src/core/TkRayTracer.cpp:43-52). */
+int tkhip_set_camera(tkhip_ctx* ctx, const float c2w[16], const float raster2cam[16],
+                     int width, int height);
+
+/* ------------------------------------------------------------ SPPM render */
+
+/* SppmTracer ctor + startRaytracing (src/tracer/TkSppmTracer.cpp:11-29,
+ * :385-398): rounds numRecurse up to x*y, allocates both photon maps and the
+ * SPPMPixel array (every pixel's radius2 = param->radius2), zeroes counters.
+ * rank/world partition the work of one iteration over `world` processes, one
+ * GPU each: rank r emits the photon paths with Halton index = r (mod world)
+ * and fills a quota of size/world photons per map, and owns the pixel rows
+ * y with (y / 8) % world == r.  world = 1 is the single-GPU case. */
+int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth,
+                     float russian_roulette, uint64_t seed, int rank, int world);
+
+/* Photon phase of iteration `iter` (tracePhoton / traceCausticPhoton loops,
+ * src/tracer/TkSppmTracer.cpp:104-217, :456-470): fills this rank's quota of
+ * both maps.  stats may be null. */
+int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* stats);
+
+/* Device pointers of this rank's freshly traced photons, for the exchange
+ * between ranks.  which: 0 global, 1 caustic.  pos and power are float[3*n]
+ * (xyz / rgb interleaved), dir is uint16[n] (theta | phi << 8).
+ * shot = paths this rank traced to fill its quota. */
+int tkhip_sppm_local_photons(tkhip_ctx* ctx, int which, const float** pos, const float** power,
+                             const uint16_t** dir, int64_t* n, int64_t* shot);
+
+/* Installs the photons of ALL ranks (device pointers, same layout) as map
+ * `which` for the coming camera pass and adds shot_total to the cumulative
+ * shoot counter.  With world = 1 this is done by tkhip_sppm_photon_pass. */
+int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, const float* power,
+                               const uint16_t* dir, int64_t n, int64_t shot_total);
+
+/* PhotonMap::buildKdTree for both maps (src/tracer/Photonmap.cpp:96-103,
+ * :132-179), as a sort-based median split on the device. */
+int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* stats);
+
+/* traceTile over this rank's pixels (src/tracer/TkSppmTracer.cpp:290-374):
+ * camera paths with next-event estimation, the caustic and global gathers
+ * (radiance_estimate, src/tracer/Photonmap.cpp:105-130) and the per-pixel
+ * flux / radius / photon-count update. */
+int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* stats);
+
+/* photon_pass + build_maps + camera_pass for world = 1: one state-machine
+ * round of SppmTracer::render (src/tracer/TkSppmTracer.cpp:447-541). */
+int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* stats);
+
+/* Copies the SPPMPixel array (width*height entries, row-major, y down as the
+ * reference indexes pp[x + y*width]) to host memory. */
+int tkhip_sppm_read_pixels(tkhip_ctx* ctx, TkSPPMPixel* host_out);
+
+/* Device pointer to the SPPMPixel array as 13 planes of width*height floats
+ * (plane order = field order of TkSPPMPixel), for the image gather between
+ * ranks.  Rows not owned by this rank hold their initial values. */
+int tkhip_sppm_pixel_planes(tkhip_ctx* ctx, float** device_planes);
+
+/* Final colour, gamma 0.6, RGB8, rows written bottom-up
+ * (src/tracer/TkSppmTracer.cpp:514-529).  host_out holds width*height*3 bytes.
+ * iterations = the divisor of Ld (numRecurse in the reference). */
+int tkhip_sppm_resolve_rgb8(tkhip_ctx* ctx, int iterations, uint8_t* host_out);
+
+/* Cumulative shoot counters and the rounded-up iteration count. */
+int tkhip_sppm_counters(tkhip_ctx* ctx, int64_t* shoot_global, int64_t* shoot_caustic,
+                        int32_t* num_recurse);
+
+/* ------------------------------------------- kernel-level entry points
+ * Used by the parity tests and by hosts that drive the phases themselves. */
+
+/* A photon map of fixed capacity with sample count k
+ * (PhotonMap::PhotonMap, src/tracer/Photonmap.cpp:20-34). */
+int tkhip_map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out);
+void tkhip_map_destroy(tkhip_map* map);
+
+/* storePhoton x n (src/tracer/Photonmap.cpp:44-53) from host arrays:
+ * pos float[3n], power float[3n], theta u8[n], phi u8[n].  Photon index i is
+ * its position in these arrays; kNN ties are broken by this index. */
+int tkhip_map_store(tkhip_map* map, const float* pos, const float* power,
+                    const uint8_t* theta, const uint8_t* phi, int64_t n);
+
+/* buildKdTree (src/tracer/Photonmap.cpp:96-103). */
+int tkhip_map_build(tkhip_map* map);
+
+/* Tree introspection for tests: number of leaves, photons per leaf (max), and
+ * a copy of the photon permutation (leaf order -> original index), host out
+ * int32[n]; perm may be null. */
+int tkhip_map_tree_info(tkhip_map* map, int32_t* n_leaves, int32_t* leaf_capacity,
+                        int32_t* depth, int32_t* perm);
+
+/* radiance_estimate for nq queries (src/tracer/Photonmap.cpp:105-130 with
+ * neighbor_search, src/tracer/neighbor.cpp:5-85).  Host arrays:
+ *   in : p float[3nq], n float[3nq], wo float[3nq], R float[3nq] (diffuse
+ *        reflectance of the surface hit), radius2 float[nq]
+ *   out: flux float[3nq] (sum of power*|wi.n|*f, no division by pi r^2),
+ *        found int32[nq], radius2_out float[nq] (= dist2[k] on return),
+ *        idx int32[nq*k] or null: the found photon indices, ascending, rest -1.
+ * mode 0: production path (grouped kernel + per-query kernel for overflow);
+ * mode 1: per-query kernel only. */
+int tkhip_map_gather(tkhip_map* map, int64_t nq, const float* p, const float* n, const float* wo,
+                     const float* R, const float* radius2, float* flux, int32_t* found,
+                     float* radius2_out, int32_t* idx, int mode);
+
+/* Scene::intersect for n rays (src/core/Scene.cpp:22-25 -> src/BVH.cpp:245-288,
+ * src/Triangle.cpp:15-52, src/Sphere.cpp:14-55).  Host arrays:
+ *   in : org float[3n], dir float[3n], tmax float[n]
+ *   out: prim int32[n] (-1 miss; triangles 0..n_tris-1, spheres n_tris+j),
+ *        t float[n], p float[3n], nrm float[3n], perr float[3n] */
+int tkhip_trace_rays(tkhip_ctx* ctx, int64_t n, const float* org, const float* dir,
+                     const float* tmax, int32_t* prim, float* t, float* p, float* nrm,
+                     float* perr);
+
+/* The flux/radius/photon-count update rule of traceTile
+ * (src/tracer/TkSppmTracer.cpp:327-340, :346-359) applied to n independent
+ * (flux rgb, photons, radius2) records with gathered (Lindir rgb, found M,
+ * returned radius2).  Host arrays, updated in place. */
+int tkhip_pixel_update(tkhip_ctx* ctx, int64_t n, float* flux, float* photons, float* radius2,
+                       const float* lindir, const int32_t* found, const float* radius2_ret);
+
+/* RadicalInverse(baseIndex, a) for n (dim, index) pairs
+ * (src/core/TkLowdiscrepancy.h:19-32).  Host arrays. */
+int tkhip_radical_inverse(tkhip_ctx* ctx, int64_t n, const int32_t* dim, const uint64_t* index,
+                          float* out);
+
+/* Camera::generateRay for n raster positions (src/core/camera.cpp:51-71).
+ * Host arrays: raster float[2n] -> org float[3n], dir float[3n]. */
+int tkhip_camera_rays(tkhip_ctx* ctx, int64_t n, const float* raster, float* org, float* dir);
+
+/* The photons of render map `which` (0 global, 1 caustic) after a photon pass,
+ * in storage (path) order, to host arrays sized by the map capacity; any out
+ * pointer may be null.  Returns the stored count in *n. */
+int tkhip_sppm_read_photons(tkhip_ctx* ctx, int which, float* pos, float* power,
+                            uint8_t* theta, uint8_t* phi, int64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TKHIP_H */

@@ -1,0 +1,243 @@
+"""ctypes wrapper of oracle/liboracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  PARITY UNPINNED: see oracle/sppm_oracle.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from pathtracer_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+f32p, i32p, i64p, u8p = _abi.c_float_p, _abi.c_int32_p, _abi.c_int64_p, _abi.c_uint8_p
+
+
+class OrcQuery(C.Structure):
+    _fields_ = [("p", C.c_float * 3), ("n", C.c_float * 3), ("wo", C.c_float * 3), ("coef", C.c_float * 3),
+                ("R", C.c_float * 3), ("pixel", C.c_int32), ("which", C.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} missing: run `make -C oracle`")
+    L = C.CDLL(path)
+    sig = {
+        "orc_radical_inverse": (C.c_float, [C.c_int32, C.c_uint64]),
+        "orc_hash_pixel": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+        "orc_permutation_element": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+        "orc_rng_u01": (C.c_float, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "orc_direction_tables": (None, [f32p, f32p, f32p, f32p]),
+        "orc_encode_direction": (None, [f32p, u8p, u8p]),
+        "orc_pixel_update": (None, [C.c_int64, f32p, f32p, f32p, f32p, i32p, f32p]),
+        "orc_resolve_rgb8": (None, [C.POINTER(_abi.TkSPPMPixel), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                    C.c_int, u8p]),
+        "orc_scene_create": (C.c_void_p, [C.POINTER(_abi.TkObject), C.c_int, C.POINTER(_abi.TkTriangle), C.c_int,
+                                          C.POINTER(_abi.TkSphere), C.c_int, C.POINTER(_abi.TkMaterial), C.c_int,
+                                          C.POINTER(_abi.TkLight), C.c_int]),
+        "orc_scene_destroy": (None, [C.c_void_p]),
+        "orc_scene_set_camera": (None, [C.c_void_p, f32p, f32p, C.c_int, C.c_int]),
+        "orc_trace_rays": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p, i32p, f32p, f32p, f32p, f32p, C.c_int]),
+        "orc_camera_rays": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p]),
+        "orc_sample_f": (None, [C.POINTER(_abi.TkMaterial), C.c_int, C.c_int64, f32p, f32p, f32p, f32p, f32p, f32p]),
+        "orc_sample_le": (None, [C.c_void_p, C.c_int, C.c_int64, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]),
+        "orc_map_create": (C.c_void_p, [C.c_int64, C.c_int]),
+        "orc_map_destroy": (None, [C.c_void_p]),
+        "orc_map_reset": (None, [C.c_void_p]),
+        "orc_map_store": (C.c_int64, [C.c_void_p, f32p, f32p, u8p, u8p, C.c_int64]),
+        "orc_map_build": (None, [C.c_void_p, C.c_int]),
+        "orc_map_gather": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p, f32p, f32p, f32p, i32p, f32p, i32p]),
+        "orc_map_gather_brute": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p, f32p, f32p, f32p, i32p, f32p, i32p]),
+        "orc_map_split_histogram": (C.c_int64, [C.c_void_p, i64p]),
+        "orc_sppm_begin": (C.c_void_p, [C.c_void_p, C.POINTER(_abi.TkSppmParam), C.c_int, C.c_float, C.c_uint64,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "orc_sppm_destroy": (None, [C.c_void_p]),
+        "orc_sppm_photon_pass": (None, [C.c_void_p, C.c_int, C.POINTER(_abi.TkIterStats)]),
+        "orc_sppm_build_maps": (None, [C.c_void_p, C.POINTER(_abi.TkIterStats)]),
+        "orc_sppm_camera_pass": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_abi.TkIterStats)]),
+        "orc_sppm_iteration": (None, [C.c_void_p, C.c_int, C.POINTER(_abi.TkIterStats)]),
+        "orc_sppm_read_pixels": (None, [C.c_void_p, C.POINTER(_abi.TkSPPMPixel)]),
+        "orc_sppm_write_pixels": (None, [C.c_void_p, C.POINTER(_abi.TkSPPMPixel)]),
+        "orc_sppm_resolve": (None, [C.c_void_p, u8p]),
+        "orc_sppm_read_photons": (C.c_int64, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, i64p]),
+        "orc_sppm_set_map_photons": (None, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, C.c_int64, C.c_int64]),
+        "orc_sppm_counters": (None, [C.c_void_p, i64p, i64p, i32p]),
+        "orc_sppm_camera_path": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(OrcQuery)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+def ip(a):
+    return a.ctypes.data_as(i32p)
+
+
+def bp(a):
+    return a.ctypes.data_as(u8p)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleScene:
+    def __init__(self, scene, width=None, height=None):
+        L = lib()
+        self.scene = scene
+        self.h = L.orc_scene_create(scene.objects, scene.n_objects, scene.triangles, scene.n_triangles,
+                                    scene.spheres, scene.n_spheres, scene.materials, scene.n_materials,
+                                    scene.lights, scene.n_lights)
+        self.width = width or scene.width
+        self.height = height or scene.height
+        c2w, r2c = scene.camera_matrices(self.width, self.height)
+        L.orc_scene_set_camera(self.h, fp(c2w), fp(r2c), self.width, self.height)
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def trace(self, org, direction, tmax=None, faithful=0):
+        org, direction = f32(org), f32(direction)
+        n = org.shape[0]
+        tm = f32(tmax) if tmax is not None else np.full(n, 3.0e38, np.float32)
+        prim = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        p = np.empty((n, 3), np.float32)
+        nrm = np.empty((n, 3), np.float32)
+        perr = np.empty((n, 3), np.float32)
+        lib().orc_trace_rays(self.h, n, fp(org), fp(direction), fp(tm), ip(prim), fp(t), fp(p), fp(nrm), fp(perr),
+                             faithful)
+        return prim, t, p, nrm, perr
+
+    def camera_rays(self, raster):
+        raster = f32(raster)
+        n = raster.shape[0]
+        org = np.empty((n, 3), np.float32)
+        d = np.empty((n, 3), np.float32)
+        lib().orc_camera_rays(self.h, n, fp(raster), fp(org), fp(d))
+        return org, d
+
+
+class OracleMap:
+    def __init__(self, capacity, k):
+        self.k = k
+        self.h = lib().orc_map_create(capacity, k)
+
+    def close(self):
+        if self.h:
+            lib().orc_map_destroy(self.h)
+            self.h = None
+
+    def store(self, pos, power, theta, phi):
+        pos, power = f32(pos), f32(power)
+        theta = np.ascontiguousarray(theta, np.uint8)
+        phi = np.ascontiguousarray(phi, np.uint8)
+        return lib().orc_map_store(self.h, fp(pos), fp(power), bp(theta), bp(phi), pos.shape[0])
+
+    def build(self, split_mode=0):
+        lib().orc_map_build(self.h, split_mode)
+
+    def gather(self, p, n, wo, R, radius2, brute=False, want_idx=True):
+        p, n, wo, R, radius2 = f32(p), f32(n), f32(wo), f32(R), f32(radius2)
+        nq = p.shape[0]
+        flux = np.empty((nq, 3), np.float32)
+        found = np.empty(nq, np.int32)
+        r2 = np.empty(nq, np.float32)
+        idx = np.empty((nq, self.k), np.int32) if want_idx else None
+        fn = lib().orc_map_gather_brute if brute else lib().orc_map_gather
+        fn(self.h, nq, fp(p), fp(n), fp(wo), fp(R), fp(radius2), fp(flux), ip(found), fp(r2),
+           ip(idx) if idx is not None else None)
+        return flux, found, r2, idx
+
+    def split_histogram(self):
+        h = np.zeros(5, np.int64)
+        lib().orc_map_split_histogram(self.h, h.ctypes.data_as(i64p))
+        return h
+
+
+class OracleSppm:
+    def __init__(self, oscene, param, max_depth, rr, seed, rank=0, world=1, threads=8, split_mode=1,
+                 faithful_bvh=0, rng_cost=0):
+        self.oscene = oscene
+        self.h = lib().orc_sppm_begin(oscene.h, C.byref(param), max_depth, rr, seed, rank, world, threads,
+                                      split_mode, faithful_bvh, rng_cost)
+
+    def close(self):
+        if self.h:
+            lib().orc_sppm_destroy(self.h)
+            self.h = None
+
+    def photon_pass(self, it):
+        st = _abi.TkIterStats()
+        lib().orc_sppm_photon_pass(self.h, it, C.byref(st))
+        return st
+
+    def build_maps(self):
+        lib().orc_sppm_build_maps(self.h, None)
+
+    def camera_pass(self, it, y0=0, y1=None):
+        st = _abi.TkIterStats()
+        lib().orc_sppm_camera_pass(self.h, it, y0, self.oscene.height if y1 is None else y1, C.byref(st))
+        return st
+
+    def iteration(self, it):
+        st = _abi.TkIterStats()
+        lib().orc_sppm_iteration(self.h, it, C.byref(st))
+        return st
+
+    def pixels(self):
+        n = self.oscene.width * self.oscene.height
+        buf = (_abi.TkSPPMPixel * n)()
+        lib().orc_sppm_read_pixels(self.h, buf)
+        return np.frombuffer(buf, dtype=np.float32).reshape(n, 13).copy()
+
+    def set_pixels(self, arr):
+        arr = f32(arr)
+        lib().orc_sppm_write_pixels(self.h, C.cast(arr.ctypes.data, C.POINTER(_abi.TkSPPMPixel)))
+
+    def resolve(self):
+        out = np.empty((self.oscene.height, self.oscene.width, 3), np.uint8)
+        lib().orc_sppm_resolve(self.h, bp(out))
+        return out
+
+    def photons(self, which, capacity):
+        pos = np.empty((capacity, 3), np.float32)
+        power = np.empty((capacity, 3), np.float32)
+        theta = np.empty(capacity, np.uint8)
+        phi = np.empty(capacity, np.uint8)
+        shot = C.c_int64()
+        n = lib().orc_sppm_read_photons(self.h, which, fp(pos), fp(power), bp(theta), bp(phi), C.byref(shot))
+        return pos[:n], power[:n], theta[:n], phi[:n], shot.value
+
+    def set_map_photons(self, which, pos, power, theta, phi, shot_total):
+        pos, power = f32(pos), f32(power)
+        theta = np.ascontiguousarray(theta, np.uint8)
+        phi = np.ascontiguousarray(phi, np.uint8)
+        lib().orc_sppm_set_map_photons(self.h, which, fp(pos), fp(power), bp(theta), bp(phi), pos.shape[0], shot_total)
+
+    def counters(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
+        lib().orc_sppm_counters(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def camera_path(self, it, x, y):
+        ld = np.zeros(3, np.float32)
+        q = (OrcQuery * 2)()
+        n = lib().orc_sppm_camera_path(self.h, it, x, y, fp(ld), q)
+        return ld, [q[i] for i in range(n)]
