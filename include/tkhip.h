@@ -182,12 +182,13 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth,
  * both maps.  stats may be null. */
 int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* stats);
 
-/* Device pointers of this rank's freshly traced photons, for the exchange
- * between ranks.  which: 0 global, 1 caustic.  pos and power are float[3*n]
- * (xyz / rgb interleaved), dir is uint16[n] (theta | phi << 8).
- * shot = paths this rank traced to fill its quota. */
-int tkhip_sppm_local_photons(tkhip_ctx* ctx, int which, const float** pos, const float** power,
-                             const uint16_t** dir, int64_t* n, int64_t* shot);
+/* Copies this rank's freshly traced photons of map `which` (0 global,
+ * 1 caustic) into caller-owned DEVICE buffers for the exchange between ranks:
+ * pos and power are float[3*cap] (xyz / rgb interleaved), dir is uint16[cap]
+ * (theta | phi << 8), cap >= this rank's quota.  *n = photons copied,
+ * *shot = light paths this rank traced to fill its quota. */
+int tkhip_sppm_export_local_photons(tkhip_ctx* ctx, int which, float* pos, float* power,
+                                    uint16_t* dir, int64_t cap, int64_t* n, int64_t* shot);
 
 /* Installs the photons of ALL ranks (device pointers, same layout) as map
  * `which` for the coming camera pass and adds shot_total to the cumulative
@@ -213,10 +214,12 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* stats);
  * reference indexes pp[x + y*width]) to host memory. */
 int tkhip_sppm_read_pixels(tkhip_ctx* ctx, TkSPPMPixel* host_out);
 
-/* Device pointer to the SPPMPixel array as 13 planes of width*height floats
- * (plane order = field order of TkSPPMPixel), for the image gather between
- * ranks.  Rows not owned by this rank hold their initial values. */
-int tkhip_sppm_pixel_planes(tkhip_ctx* ctx, float** device_planes);
+/* The SPPMPixel array as 13 planes of width*height floats (plane order =
+ * field order of TkSPPMPixel) copied to / from a caller-owned DEVICE buffer,
+ * for the image gather between ranks.  Rows not owned by a rank hold their
+ * initial values there. */
+int tkhip_sppm_export_planes(tkhip_ctx* ctx, float* device_dst);
+int tkhip_sppm_import_planes(tkhip_ctx* ctx, const float* device_src);
 
 /* Final colour, gamma 0.6, RGB8, rows written bottom-up
  * (src/tracer/TkSppmTracer.cpp:514-529).  host_out holds width*height*3 bytes.

@@ -89,15 +89,16 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_begin": (C.c_int, [C.c_void_p, C.POINTER(TkSppmParam), C.c_int, C.c_float, C.c_uint64,
                                    C.c_int, C.c_int]),
     "tkhip_sppm_photon_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
-    "tkhip_sppm_local_photons": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                           C.POINTER(C.c_void_p), c_int64_p, c_int64_p]),
+    "tkhip_sppm_export_local_photons": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int64, c_int64_p, c_int64_p]),
     "tkhip_sppm_set_map_photons": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_int64]),
     "tkhip_sppm_build_maps": (C.c_int, [C.c_void_p, C.POINTER(TkIterStats)]),
     "tkhip_sppm_camera_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_read_pixels": (C.c_int, [C.c_void_p, C.POINTER(TkSPPMPixel)]),
-    "tkhip_sppm_pixel_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tkhip_sppm_export_planes": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tkhip_sppm_import_planes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tkhip_sppm_resolve_rgb8": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p]),
     "tkhip_sppm_counters": (C.c_int, [C.c_void_p, c_int64_p, c_int64_p, c_int32_p]),
     "tkhip_map_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),

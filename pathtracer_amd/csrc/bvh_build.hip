@@ -1,0 +1,221 @@
+// bvh_build.hip — host-side construction of the flat scene BVH.
+//
+// Replaces the CPU renderer's per-object hierarchy (top-level BVH over objects
+// plus one BVH per mesh, SAH with 12 buckets, one primitive per leaf:
+// src/BVH.cpp:62-243, src/core/Scene.cpp:18-20, src/Triangle.cpp:179) by a
+// single binned-SAH tree over every triangle and sphere, laid out for the GPU:
+// 64-byte nodes that carry both child boxes, leaves of up to four primitives
+// referenced straight from the parent, primitives reordered into leaf order.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "tk_common.h"
+
+namespace tkd {
+
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -mn[a]; }
+    }
+    void grow(const Box& b) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); }
+    }
+    void grow(const float p[3]) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    double area() const {
+        double dx = double(mx[0]) - mn[0], dy = double(mx[1]) - mn[1], dz = double(mx[2]) - mn[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0;
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+};
+
+struct Prim {
+    Box b;
+    float c[3];
+    int32_t id;
+};
+
+struct TmpNode {
+    Box b;
+    int32_t left = -1, right = -1;   // TmpNode indices
+    int32_t first = 0, count = 0;    // leaf: slot range
+};
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<TmpNode> nodes;
+    std::vector<int32_t> order;
+    int max_leaf = 4;
+    int depth_limit = 32;
+    bool median_only = false;
+    int max_depth = 0;
+
+    int32_t build(int start, int end, int depth) {
+        int32_t me = int32_t(nodes.size());
+        nodes.emplace_back();
+        max_depth = std::max(max_depth, depth);
+        Box b, cb;
+        b.reset();
+        cb.reset();
+        for (int i = start; i < end; ++i) { b.grow(prims[i].b); cb.grow(prims[i].c); }
+        nodes[me].b = b;
+        int n = end - start;
+        auto make_leaf = [&]() {
+            nodes[me].first = int32_t(order.size());
+            nodes[me].count = n;
+            for (int i = start; i < end; ++i) order.push_back(prims[i].id);
+            return me;
+        };
+        if (n == 1) return make_leaf();
+        int axis = 0;
+        float ext[3] = {cb.mx[0] - cb.mn[0], cb.mx[1] - cb.mn[1], cb.mx[2] - cb.mn[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        int mid = -1;
+        bool force_median = median_only || depth >= depth_limit;
+        if (ext[axis] <= 0) {
+            if (n <= max_leaf) return make_leaf();
+            mid = (start + end) / 2;   // coincident centroids: split by count
+        } else if (!force_median) {
+            constexpr int NB = 16;
+            int cnt[NB] = {0};
+            Box bb[NB];
+            for (auto& x : bb) x.reset();
+            float k1 = NB * (1.0f - 1e-6f) / ext[axis];
+            for (int i = start; i < end; ++i) {
+                int bi = std::min(NB - 1, std::max(0, int(k1 * (prims[i].c[axis] - cb.mn[axis]))));
+                cnt[bi]++;
+                bb[bi].grow(prims[i].b);
+            }
+            double la[NB - 1], ra[NB - 1];
+            int lc[NB - 1], rc[NB - 1];
+            Box acc;
+            acc.reset();
+            int c = 0;
+            for (int i = 0; i < NB - 1; ++i) { acc.grow(bb[i]); c += cnt[i]; la[i] = acc.area(); lc[i] = c; }
+            acc.reset();
+            c = 0;
+            for (int i = NB - 1; i > 0; --i) { acc.grow(bb[i]); c += cnt[i]; ra[i - 1] = acc.area(); rc[i - 1] = c; }
+            double best = std::numeric_limits<double>::infinity();
+            int best_i = -1;
+            for (int i = 0; i < NB - 1; ++i) {
+                if (lc[i] == 0 || rc[i] == 0) continue;
+                double cost = lc[i] * la[i] + rc[i] * ra[i];
+                if (cost < best) { best = cost; best_i = i; }
+            }
+            const double c_trav = 1.0, c_isect = 1.5;
+            double parent_area = std::max(b.area(), 1e-30);
+            double split_cost = c_trav + c_isect * best / parent_area;
+            if (n <= max_leaf && (best_i < 0 || split_cost >= c_isect * n)) return make_leaf();
+            if (best_i >= 0) {
+                auto it = std::partition(prims.begin() + start, prims.begin() + end, [&](const Prim& p) {
+                    int bi = std::min(NB - 1, std::max(0, int(k1 * (p.c[axis] - cb.mn[axis]))));
+                    return bi <= best_i;
+                });
+                mid = int(it - prims.begin());
+            }
+        }
+        if (mid <= start || mid >= end) {
+            if (n <= max_leaf && force_median) return make_leaf();
+            mid = (start + end) / 2;
+            std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
+                             [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis]; });
+        }
+        int32_t l = build(start, mid, depth + 1);
+        int32_t r = build(mid, end, depth + 1);
+        nodes[me].left = l;
+        nodes[me].right = r;
+        return me;
+    }
+};
+
+int32_t encode_leaf(const TmpNode& n) { return ~(n.first * 8 + (n.count - 1)); }
+
+}  // namespace
+
+void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int n_spheres, int max_leaf,
+               int max_stack_depth, HostBvh* out) {
+    out->nodes.clear();
+    out->order.clear();
+    out->root_leaf = 0x7fffffff;
+    out->max_depth = 0;
+    for (int a = 0; a < 3; ++a) { out->bmin[a] = 0; out->bmax[a] = 0; }
+    int n = n_tris + n_spheres;
+    if (n == 0) return;
+    Builder bld;
+    bld.max_leaf = std::min(max_leaf, 8);
+    bld.prims.resize(size_t(n));
+    for (int i = 0; i < n_tris; ++i) {
+        Prim& p = bld.prims[size_t(i)];
+        p.b.reset();
+        p.b.grow(tris[i].v0);
+        p.b.grow(tris[i].v1);
+        p.b.grow(tris[i].v2);
+        p.id = i;
+    }
+    for (int j = 0; j < n_spheres; ++j) {
+        Prim& p = bld.prims[size_t(n_tris + j)];
+        // pad by a few ulps: the hit point is re-projected onto the sphere
+        float r = spheres[j].radius * 1.00001f;
+        for (int a = 0; a < 3; ++a) { p.b.mn[a] = spheres[j].center[a] - r; p.b.mx[a] = spheres[j].center[a] + r; }
+        p.id = n_tris + j;
+    }
+    for (auto& p : bld.prims)
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.b.mn[a] + 0.5f * p.b.mx[a];
+    std::vector<Prim> saved = bld.prims;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bld.nodes.clear();
+        bld.order.clear();
+        bld.max_depth = 0;
+        bld.median_only = attempt == 1;
+        bld.depth_limit = max_stack_depth - 12;
+        bld.nodes.reserve(size_t(n) * 2);
+        bld.order.reserve(size_t(n));
+        if (attempt == 1) bld.prims = saved;
+        bld.build(0, n, 0);
+        if (bld.max_depth < max_stack_depth - 1) break;
+    }
+    out->max_depth = bld.max_depth;
+    out->order = bld.order;
+    const TmpNode& root = bld.nodes[0];
+    for (int a = 0; a < 3; ++a) { out->bmin[a] = root.b.mn[a]; out->bmax[a] = root.b.mx[a]; }
+    if (root.left < 0) {
+        out->root_leaf = ~encode_leaf(root);
+        return;
+    }
+    // number the interior nodes in depth-first order
+    std::vector<int32_t> flat(bld.nodes.size(), -1);
+    int32_t count = 0;
+    std::vector<int32_t> stack{0};
+    while (!stack.empty()) {
+        int32_t t = stack.back();
+        stack.pop_back();
+        const TmpNode& tn = bld.nodes[size_t(t)];
+        if (tn.left < 0) continue;
+        flat[size_t(t)] = count++;
+        stack.push_back(tn.right);
+        stack.push_back(tn.left);
+    }
+    out->nodes.resize(size_t(count));
+    for (size_t t = 0; t < bld.nodes.size(); ++t) {
+        if (flat[t] < 0) continue;
+        const TmpNode& tn = bld.nodes[t];
+        const TmpNode& L = bld.nodes[size_t(tn.left)];
+        const TmpNode& R = bld.nodes[size_t(tn.right)];
+        BvhNode& o = out->nodes[size_t(flat[t])];
+        for (int a = 0; a < 3; ++a) {
+            o.lmin[a] = L.b.mn[a]; o.lmax[a] = L.b.mx[a];
+            o.rmin[a] = R.b.mn[a]; o.rmax[a] = R.b.mx[a];
+        }
+        o.left = L.left < 0 ? encode_leaf(L) : flat[size_t(tn.left)];
+        o.right = R.left < 0 ? encode_leaf(R) : flat[size_t(tn.right)];
+        o.pad0 = o.pad1 = 0;
+    }
+}
+
+}  // namespace tkd

@@ -1,0 +1,67 @@
+// photon_map.h — device photon map: storage, sort-based KD-tree, kNN gather.
+#pragma once
+#include "tk_common.h"
+
+namespace tkd {
+
+constexpr int kLeafCap = 32;   // photons per KD leaf (at most; at least half)
+
+// Queries of one gather launch, struct-of-arrays on the device.
+struct QueryView {
+    const float4* q0;   // p.xyz, search radius^2
+    const float4* q1;   // n.xyz, dot(wo, n)
+    const float4* q2;   // path throughput rgb, pixel index (int bits)
+    const float4* q3;   // BRDF value R/pi rgb, unused
+};
+
+// Where results go.  Test outputs are indexed by query; the render output is
+// the fused per-pixel flux / photon count / radius update.
+struct GatherOut {
+    float* flux;        // 3 per query or null
+    int32_t* found;     // or null
+    float* r2out;       // or null
+    int32_t* idx;       // k per query or null
+    float* planes;      // SPPMPixel planes (13 x n_pixels) or null
+    int64_t n_pixels;
+    int32_t which;      // 0 global, 1 caustic: selects the planes to update
+    unsigned long long* photon_sum;   // optional: sum of found over queries
+};
+
+struct MapView {
+    const float4* pos4;      // leaf order: x, y, z, original index (int bits)
+    const float4* pow4;      // leaf order: r, g, b, theta | phi << 8 (int bits)
+    const float4* node_box;  // heap order, 2 float4 per node: (mnx,mny,mnz,mxx) (mxy,mxz,-,-)
+    const float* dirtab;     // cosTheta[256], sinTheta[256], cosPhi[256], sinPhi[256]
+    int32_t n, nl, depth, k;
+};
+
+}  // namespace tkd
+
+struct tkhip_map {
+    tkhip_ctx* ctx = nullptr;
+    int64_t cap = 0, n = 0;
+    int k = 0;
+    bool built = false;
+    int nl = 0, depth = 0;
+    float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
+    tkd::DevBuf in_pos, in_pow, in_dir;            // storage order: float3, float3, u16
+    tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
+    tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
+    tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
+    float last_group_ms = 0.f;   // duration of the last grouped gather kernel
+    tkd::MapView view() const;
+};
+
+namespace tkd {
+
+int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out);
+void map_destroy(tkhip_map* m);
+// Device pointers, storage order.  Asynchronous copy on the context stream.
+int map_set_photons_device(tkhip_map* m, const float* pos, const float* power, const uint16_t* dir, int64_t n);
+int map_build(tkhip_map* m);
+// nq queries on the device -> out.  mode 0: grouped kernel then per-query
+// kernel for the overflow; mode 1: per-query kernel only.  timed: record the
+// grouped kernel's duration with events (synchronises).
+int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed);
+
+}  // namespace tkd

@@ -1,0 +1,888 @@
+// photon_map.hip — the photon map on the device.
+//
+//  * storage  : PhotonMap::storePhoton (src/tracer/Photonmap.cpp:44-53)
+//  * build    : PhotonMap::buildKdTree / balance (src/tracer/Photonmap.cpp:96-103, :132-179)
+//               as a sort-based median split: per level one radix sort of
+//               (node id, coordinate on the node's widest axis) keys; the tree
+//               is implicit (complete binary tree, photon ranges by arithmetic)
+//  * gather   : neighbor_search + radiance_estimate (src/tracer/neighbor.cpp:5-85,
+//               src/tracer/Photonmap.cpp:105-130) with the fused per-pixel update of
+//               traceTile (src/tracer/TkSppmTracer.cpp:327-340, :346-359)
+//
+// Result contract of a gather (what the CPU code computes, stated without its
+// traversal order): among the photons with dist2 < radius2 (strict) keep the k
+// smallest by (dist2, photon index); found = how many were kept; the returned
+// radius2 is the largest kept dist2 when k were kept and the input radius2
+// otherwise; flux = sum over the kept photons of power * |wi.n| * f.
+// dist2 is ((dx*dx + dy*dy) + dz*dz) in fp32 with separate roundings.
+#include "photon_map.h"
+
+#include <algorithm>
+
+#include "tk_device.h"
+
+namespace tkd {
+
+// ------------------------------------------------------------ small helpers
+TKD uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+TKD float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+TKD int64_t leaf_start(int64_t j, int64_t n, int64_t nl) { return j * n / nl; }
+TKD int leaf_of_pos(int64_t i, int64_t n, int64_t nl) { return (int)(((i + 1) * nl - 1) / n); }
+
+TKD float dist2_exact(float px, float py, float pz, F3 q) {
+    float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+TKD float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+TKD float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+TKD float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+TKD unsigned long long wave_max_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+TKD float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+TKD int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+TKD float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// ---------------------------------------------------------------- build
+__global__ void k_iota(uint32_t* a, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+
+__global__ void k_root_box_init(uint32_t* box6) {
+    if (threadIdx.x < 3) box6[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) box6[threadIdx.x] = 0u;
+}
+__global__ void k_root_box(const float* pos, int64_t n, uint32_t* box6) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            float v = pos[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    for (int a = 0; a < 3; ++a) {
+        float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&box6[a], f2ord(lo));
+            atomicMax(&box6[3 + a], f2ord(hi));
+        }
+    }
+}
+// clip_box: 6 floats per heap node (min xyz, max xyz); node 1 is the root.
+__global__ void k_root_finish(const uint32_t* box6, float* clip_box) {
+    if (threadIdx.x < 6) clip_box[6 + threadIdx.x] = ord2f(box6[threadIdx.x]);
+}
+
+// Bounds3::maxExtent on the clipped node box (src/Bounds3.hpp:32-41,
+// src/tracer/Photonmap.cpp:136, :149-152, :167-170)
+__global__ void k_level_axis(const float* clip_box, int32_t* node_axis, int level) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int count = 1 << level;
+    if (j >= count) return;
+    int node = count + j;
+    const float* b = clip_box + 6 * (int64_t)node;
+    float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
+    node_axis[node] = axis;
+}
+
+__global__ void k_level_keys(const float* pos, const uint32_t* idx, const int32_t* node_axis, uint64_t* keys,
+                             int64_t n, int nl, int depth, int level) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int leaf = leaf_of_pos(i, n, nl);
+    int j = leaf >> (depth - level);
+    int axis = node_axis[(1 << level) + j];
+    float v = pos[3 * (int64_t)idx[i] + axis];
+    keys[i] = ((uint64_t)(uint32_t)j << 32) | f2ord(v);
+}
+
+// The median photon (first of the right half) fixes the split plane; children
+// inherit the parent box clipped at it.
+__global__ void k_level_split(const float* pos, const uint32_t* idx, float* clip_box, const int32_t* node_axis,
+                              int64_t n, int nl, int depth, int level) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int count = 1 << level;
+    if (j >= count) return;
+    int node = count + j;
+    int axis = node_axis[node];
+    int mid_leaf = (2 * j + 1) << (depth - level - 1);
+    int64_t mid = leaf_start(mid_leaf, n, nl);
+    float split = pos[3 * (int64_t)idx[mid] + axis];
+    const float* b = clip_box + 6 * (int64_t)node;
+    float* l = clip_box + 6 * (int64_t)(2 * node);
+    float* r = clip_box + 6 * (int64_t)(2 * node + 1);
+    for (int a = 0; a < 6; ++a) { l[a] = b[a]; r[a] = b[a]; }
+    l[3 + axis] = split;
+    r[axis] = split;
+}
+
+__global__ void k_permute(const float* pos, const float* pow, const uint16_t* dir, const uint32_t* idx,
+                          float4* pos4, float4* pow4, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = idx[i];
+    pos4[i] = make_float4(pos[3 * (int64_t)s], pos[3 * (int64_t)s + 1], pos[3 * (int64_t)s + 2], __uint_as_float(s));
+    pow4[i] = make_float4(pow[3 * (int64_t)s], pow[3 * (int64_t)s + 1], pow[3 * (int64_t)s + 2],
+                          __uint_as_float((uint32_t)dir[s]));
+}
+
+__global__ void k_leaf_boxes(const float4* pos4, float4* node_box, int64_t n, int nl) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nl) return;
+    int64_t s = leaf_start(j, n, nl), e = leaf_start(j + 1, n, nl);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = s; i < e; ++i) {
+        float4 p = pos4[i];
+        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    }
+    int node = nl + j;
+    node_box[2 * (int64_t)node] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+    node_box[2 * (int64_t)node + 1] = make_float4(mx[1], mx[2], 0.f, 0.f);
+}
+__global__ void k_inner_boxes(float4* node_box, int level) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int count = 1 << level;
+    if (j >= count) return;
+    int64_t node = count + j;
+    float4 a0 = node_box[4 * node], a1 = node_box[4 * node + 1];
+    float4 b0 = node_box[4 * node + 2], b1 = node_box[4 * node + 3];
+    node_box[2 * node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
+    node_box[2 * node + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), 0.f, 0.f);
+}
+
+// --------------------------------------------------------------- queries
+struct QLoad {
+    F3 p, n, coef, f;
+    float r2, won;
+    int pixel;
+};
+TKD QLoad load_query(const QueryView& qv, int64_t q) {
+    float4 a = qv.q0[q], b = qv.q1[q], c = qv.q2[q], d = qv.q3[q];
+    QLoad Q;
+    Q.p = mk3(a.x, a.y, a.z); Q.r2 = a.w;
+    Q.n = mk3(b.x, b.y, b.z); Q.won = b.w;
+    Q.coef = mk3(c.x, c.y, c.z); Q.pixel = __float_as_int(c.w);
+    Q.f = mk3(d.x, d.y, d.z);
+    return Q;
+}
+
+// The flux / photon count / radius rule of traceTile
+// (src/tracer/TkSppmTracer.cpp:327-340 caustic, :346-359 global).
+TKD void pixel_update(float* fr, float* fg, float* fb, float* photons, float* radius2, F3 lindir, int found,
+                      float r2ret) {
+    if (*photons == 0) {
+        *radius2 = r2ret;
+        *photons = (float)found;
+        *fr = lindir.x; *fg = lindir.y; *fb = lindir.z;
+    } else {
+        float new_photons = (float)((double)*photons + 0.7 * (double)found);
+        float new_radius2 = *radius2 * new_photons / (*photons + (float)found);
+        *fr = (*fr + lindir.x) * new_radius2 / *radius2;
+        *fg = (*fg + lindir.y) * new_radius2 / *radius2;
+        *fb = (*fb + lindir.z) * new_radius2 / *radius2;
+        *photons = new_photons;
+        *radius2 = new_radius2;
+    }
+}
+
+TKD void finish_query(const GatherOut& out, int64_t q, const QLoad& Q, int found, float r2ret, F3 S) {
+    F3 est = mul3(S, Q.f);
+    if (out.flux) { out.flux[3 * q] = est.x; out.flux[3 * q + 1] = est.y; out.flux[3 * q + 2] = est.z; }
+    if (out.found) out.found[q] = found;
+    if (out.r2out) out.r2out[q] = r2ret;
+    if (out.planes) {
+        F3 lind = mul3(Q.coef, est);
+        const int64_t np = out.n_pixels, px = Q.pixel;
+        const int fl = out.which == 0 ? 6 : 3, pn = out.which == 0 ? 10 : 9, pr = out.which == 0 ? 12 : 11;
+        float* P = out.planes;
+        float r = P[fl * np + px], g = P[(fl + 1) * np + px], b = P[(fl + 2) * np + px];
+        float photons = P[pn * np + px], radius2 = P[pr * np + px];
+        pixel_update(&r, &g, &b, &photons, &radius2, lind, found, r2ret);
+        P[fl * np + px] = r; P[(fl + 1) * np + px] = g; P[(fl + 2) * np + px] = b;
+        P[pn * np + px] = photons; P[pr * np + px] = radius2;
+    }
+}
+
+// wi decoded from the two direction bytes (src/tracer/Photonmap.cpp:122-123)
+TKD F3 decode_dir(const float* tab, uint32_t bits) {
+    uint32_t th = bits & 255u, ph = (bits >> 8) & 255u;
+    float st = tab[256 + th];
+    return mk3(st * tab[512 + ph], st * tab[768 + ph], tab[th]);
+}
+
+// Conservative squared distance from a point to a node box (never above the
+// distance of any photon inside the box).
+TKD float box_dist2(const MapView& mv, int node, F3 p) {
+    float4 b0 = mv.node_box[2 * (int64_t)node], b1 = mv.node_box[2 * (int64_t)node + 1];
+    float dx = fmaxf(fmaxf(b0.x - p.x, p.x - b0.w), 0.f);
+    float dy = fmaxf(fmaxf(b0.y - p.y, p.y - b1.x), 0.f);
+    float dz = fmaxf(fmaxf(b0.z - p.z, p.z - b1.y), 0.f);
+    return (dx * dx + dy * dy + dz * dz) * 0.999999f;
+}
+
+// ------------------------------------------- per-query kernel (one wave each)
+// The wave keeps the candidates of its query in an LDS buffer of 64*EPL
+// (dist2, index) keys and, whenever the buffer could overflow, cuts it back to
+// the k smallest with a radix select over the key bits; the k-th key then
+// becomes the new search bound.  This is the bounded max-heap of
+// neighbor_search (src/tracer/neighbor.cpp:31-83) restated for 64 lanes.
+
+template <int EPL>
+TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay, int* count_io, int k, int lane) {
+    int count = *count_io;
+    const int nchunk = (count + 63) >> 6;
+    // k-th smallest high word (dist2 bits; non-negative floats order as integers)
+    uint32_t prefix = 0;
+    int kk = k;
+    for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t above = ~((2u << bit) - 1u);
+        int c0 = 0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            int e = ch * 64 + lane;
+            bool t = false;
+            if (e < count) {
+                uint32_t hi = (uint32_t)(keys[e] >> 32);
+                t = ((hi & above) == prefix) && !((hi >> bit) & 1u);
+            }
+            c0 += __popcll(__ballot(t));
+        }
+        if (kk > c0) { kk -= c0; prefix |= 1u << bit; }
+    }
+    const uint32_t tau = prefix;
+    int less = 0, eq = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        int e = ch * 64 + lane;
+        uint32_t hi = e < count ? (uint32_t)(keys[e] >> 32) : 0xffffffffu;
+        less += __popcll(__ballot(e < count && hi < tau));
+        eq += __popcll(__ballot(e < count && hi == tau));
+    }
+    uint32_t tau_lo = 0xffffffffu;
+    if (less + eq > k) {
+        // more photons tie at the k-th distance than fit: lower index wins
+        int need = k - less;
+        uint32_t pl = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t above = bit == 31 ? 0u : ~((2u << bit) - 1u);
+            int c0 = 0;
+            for (int ch = 0; ch < nchunk; ++ch) {
+                int e = ch * 64 + lane;
+                bool t = false;
+                if (e < count) {
+                    unsigned long long key = keys[e];
+                    uint32_t lo = (uint32_t)key;
+                    t = ((uint32_t)(key >> 32) == tau) && ((lo & above) == pl) && !((lo >> bit) & 1u);
+                }
+                c0 += __popcll(__ballot(t));
+            }
+            if (need > c0) { need -= c0; pl |= 1u << bit; }
+        }
+        tau_lo = pl;
+    }
+    const unsigned long long cut = ((unsigned long long)tau << 32) | tau_lo;
+    // compact in place: chunk c only writes below what it has read
+    int w = 0;
+    unsigned long long kmax = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        int e = ch * 64 + lane;
+        unsigned long long key = 0;
+        uint32_t p = 0;
+        bool keep = false;
+        if (e < count) { key = keys[e]; p = pay[e]; keep = key <= cut; }
+        unsigned long long m = __ballot(keep);
+        int dst = w + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) { keys[dst] = key; pay[dst] = p; kmax = key > kmax ? key : kmax; }
+        w += __popcll(m);
+    }
+    *count_io = w;
+    return wave_max_u64(kmax);
+}
+
+template <int EPL>
+__global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, const int32_t* list,
+                                                     const int32_t* list_count, int64_t nq, GatherOut out) {
+    constexpr int CAP = 64 * EPL;
+    __shared__ unsigned long long s_keys[4][CAP];
+    __shared__ uint32_t s_pay[4][CAP];
+    __shared__ int s_node[4][64];
+    __shared__ float s_nd2[4][64];
+    __shared__ float s_tab[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long* keys = s_keys[wave];
+    uint32_t* pay = s_pay[wave];
+    int* st_node = s_node[wave];
+    float* st_d2 = s_nd2[wave];
+    const int64_t total = list ? (int64_t)*list_count : nq;
+    const int k = mv.k;
+    unsigned long long found_sum = 0;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < total; w += (int64_t)gridDim.x * 4) {
+        const int64_t q = list ? (int64_t)list[w] : w;
+        const QLoad Q = load_query(qv, q);
+        unsigned long long bound = (unsigned long long)__float_as_uint(Q.r2) << 32;
+        float bound_d2 = Q.r2;
+        int count = 0;
+        bool valid_r = Q.r2 > 0.f;
+        int sp = 0;
+        if (mv.n > 0 && valid_r) { st_node[0] = 1; st_d2[0] = 0.f; sp = 1; }
+        while (sp > 0) {
+            --sp;
+            const int node = uniform_i(st_node[sp]);
+            const float nd2 = uniform_f(st_d2[sp]);
+            if (!(nd2 < bound_d2)) continue;
+            if (node < mv.nl) {
+                const int c0 = 2 * node, c1 = c0 + 1;
+                const float d0 = box_dist2(mv, c0, Q.p), d1 = box_dist2(mv, c1, Q.p);
+                const bool near0 = d0 <= d1;
+                const int nn = near0 ? c0 : c1, fn = near0 ? c1 : c0;
+                const float dn = near0 ? d0 : d1, df = near0 ? d1 : d0;
+                if (df < bound_d2) { if (lane == 0) { st_node[sp] = fn; st_d2[sp] = df; } ++sp; }
+                if (dn < bound_d2) { if (lane == 0) { st_node[sp] = nn; st_d2[sp] = dn; } ++sp; }
+            } else {
+                const int leaf = node - mv.nl;
+                const int64_t s = leaf_start(leaf, mv.n, mv.nl), e = leaf_start(leaf + 1, mv.n, mv.nl);
+                const int cnt = (int)(e - s);
+                bool acc = false;
+                unsigned long long key = 0;
+                if (lane < cnt) {
+                    float4 pp = mv.pos4[s + lane];
+                    float d2 = dist2_exact(pp.x, pp.y, pp.z, Q.p);
+                    key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(pp.w);
+                    acc = key < bound;
+                }
+                unsigned long long m = __ballot(acc);
+                if (m) {
+                    int dst = count + __popcll(m & ((1ull << lane) - 1ull));
+                    if (acc) { keys[dst] = key; pay[dst] = (uint32_t)(s + lane); }
+                    count += __popcll(m);
+                    if (count > CAP - 64) {
+                        bound = wave_select_prune<EPL>(keys, pay, &count, k, lane);
+                        bound_d2 = __uint_as_float((uint32_t)(bound >> 32));
+                        // a photon exactly at the k-th distance can still win on its index
+                        bound_d2 = __uint_as_float(__float_as_uint(bound_d2) + 1u);
+                    }
+                }
+            }
+        }
+        float r2ret = Q.r2;
+        if (count >= k) {
+            unsigned long long kmax;
+            if (count > k) kmax = wave_select_prune<EPL>(keys, pay, &count, k, lane);
+            else {
+                unsigned long long mine = 0;
+                for (int e = lane; e < count; e += 64) mine = keys[e] > mine ? keys[e] : mine;
+                kmax = wave_max_u64(mine);
+            }
+            r2ret = __uint_as_float((uint32_t)(kmax >> 32));
+        }
+        float sx = 0, sy = 0, sz = 0;
+        for (int e = lane; e < count; e += 64) {
+            float4 pw = mv.pow4[pay[e]];
+            F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
+            float c = wi.x * Q.n.x + wi.y * Q.n.y + wi.z * Q.n.z;
+            if (Q.won * c > 0) {
+                float ac = fabsf(c);
+                sx += pw.x * ac; sy += pw.y * ac; sz += pw.z * ac;
+            }
+            if (out.idx) out.idx[q * k + e] = (int32_t)(uint32_t)keys[e];
+        }
+        if (out.idx) for (int e = count + lane; e < k; e += 64) out.idx[q * k + e] = -1;
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (lane == 0) finish_query(out, q, Q, count, r2ret, mk3(sx, sy, sz));
+        found_sum += (unsigned long long)count;
+    }
+    if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
+}
+
+// ---------------------------------------- grouped kernel (64 queries per wave)
+// Queries arrive sorted along a Morton curve, so the 64 of a wave are
+// neighbours in space.  The wave walks the tree once with the union of their
+// search boxes; every photon of an overlapping leaf is broadcast from the lane
+// that loaded it and tested by all 64 queries at once.  A query that meets
+// fewer than k photons inside its radius is finished here (no selection is
+// needed: found < k keeps them all and leaves the radius unchanged); the rest
+// go to the per-query kernel.
+__global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, const uint32_t* order, int64_t nq,
+                                                      GatherOut out, int32_t* overflow, int32_t* overflow_count) {
+    __shared__ float s_tab[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = mv.k;
+    const int64_t ngroups = (nq + 63) >> 6;
+    unsigned long long found_sum = 0;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
+        const int64_t slot = g * 64 + lane;
+        const bool valid = slot < nq;
+        const int64_t q = valid ? (int64_t)order[slot] : 0;
+        QLoad Q = load_query(qv, q);
+        if (!valid || !(Q.r2 > 0.f)) Q.r2 = -1.f;
+        const float rr = Q.r2 > 0.f ? sqrtf(Q.r2) * 1.00001f : -INFINITY;
+        // union of the search boxes of the wave
+        const float lox = uniform_f(wave_min(Q.r2 > 0.f ? Q.p.x - rr : INFINITY));
+        const float loy = uniform_f(wave_min(Q.r2 > 0.f ? Q.p.y - rr : INFINITY));
+        const float loz = uniform_f(wave_min(Q.r2 > 0.f ? Q.p.z - rr : INFINITY));
+        const float hix = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.x + rr : -INFINITY));
+        const float hiy = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.y + rr : -INFINITY));
+        const float hiz = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.z + rr : -INFINITY));
+        const float r2lo = Q.r2 * 0.999999f, r2hi = Q.r2 * 1.000001f;
+        int cnt = 0;
+        float sx = 0, sy = 0, sz = 0;
+        if (mv.n > 0 && lox <= hix) {
+            // stackless depth-first walk of the implicit tree (heap numbering)
+            int node = 1;
+            do {
+                node = uniform_i(node);
+                const float4 b0 = mv.node_box[2 * (int64_t)node], b1 = mv.node_box[2 * (int64_t)node + 1];
+                const bool overlap = b0.x <= hix && b0.w >= lox && b0.y <= hiy && b1.x >= loy && b0.z <= hiz && b1.y >= loz;
+                if (overlap && node < mv.nl) { node = 2 * node; continue; }
+                if (overlap) {
+                    const int leaf = node - mv.nl;
+                    const int64_t s = leaf_start(leaf, mv.n, mv.nl), e = leaf_start(leaf + 1, mv.n, mv.nl);
+                    const int n_in = (int)(e - s);
+                    float px = 0, py = 0, pz = 0, pid = 0, wr = 0, wg = 0, wb = 0, wix = 0, wiy = 0, wiz = 0;
+                    if (lane < n_in) {
+                        float4 pp = mv.pos4[s + lane], pw = mv.pow4[s + lane];
+                        px = pp.x; py = pp.y; pz = pp.z; pid = pp.w;
+                        wr = pw.x; wg = pw.y; wb = pw.z;
+                        F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
+                        wix = wi.x; wiy = wi.y; wiz = wi.z;
+                    }
+                    for (int c = 0; c < n_in; ++c) {
+                        const float cx = lane_f(px, c), cy = lane_f(py, c), cz = lane_f(pz, c);
+                        const float dx = cx - Q.p.x, dy = cy - Q.p.y, dz = cz - Q.p.z;
+                        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        bool acc = d2f < r2hi;
+                        if (__any(acc)) {
+                            if (acc && !(d2f < r2lo)) acc = (dx * dx + dy * dy + dz * dz) < Q.r2;   // borderline: exact rule
+                            const float ax = lane_f(wix, c), ay = lane_f(wiy, c), az = lane_f(wiz, c);
+                            const float cs = ax * Q.n.x + ay * Q.n.y + az * Q.n.z;
+                            if (acc) {
+                                if (out.idx && cnt < k) out.idx[q * k + cnt] = __float_as_int(lane_f(pid, c));
+                                ++cnt;
+                                if (Q.won * cs > 0) {
+                                    const float ac = fabsf(cs);
+                                    sx += lane_f(wr, c) * ac; sy += lane_f(wg, c) * ac; sz += lane_f(wb, c) * ac;
+                                }
+                            }
+                        }
+                    }
+                }
+                node = (node + 1) >> __builtin_ctz((unsigned)(node + 1));
+            } while (node != 1);
+        }
+        const bool over = valid && cnt >= k;
+        if (valid && !over) finish_query(out, q, Q, cnt, Q.r2 > 0.f ? Q.r2 : qv.q0[q].w, mk3(sx, sy, sz));
+        int dst = wave_append(overflow_count, over);
+        if (over) overflow[dst] = (int32_t)q;
+        float fs = wave_sum(valid && !over ? (float)cnt : 0.f);
+        found_sum += (unsigned long long)fs;
+    }
+    if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
+}
+
+// Morton key of the query position inside the scene/photon bounds, 10 bits per axis.
+TKD uint32_t spread10(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void k_query_morton(QueryView qv, int64_t nq, F3 bmin, F3 binv, uint32_t* keys, uint32_t* vals) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    float4 a = qv.q0[i];
+    float fx = fminf(fmaxf((a.x - bmin.x) * binv.x, 0.f), 1023.f);
+    float fy = fminf(fmaxf((a.y - bmin.y) * binv.y, 0.f), 1023.f);
+    float fz = fminf(fmaxf((a.z - bmin.z) * binv.z, 0.f), 1023.f);
+    keys[i] = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+    vals[i] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------ host side
+int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
+    TK_REQUIRE(ctx && out, TKHIP_E_ARG, "map_create: null argument");
+    TK_REQUIRE(capacity >= 0 && capacity < (int64_t)1 << 31, TKHIP_E_LIMIT, "map_create: capacity %lld out of range",
+               (long long)capacity);
+    TK_REQUIRE(k >= 1 && k <= TKHIP_MAX_K, TKHIP_E_LIMIT, "map_create: sample count %d outside 1..%d", k, TKHIP_MAX_K);
+    tkhip_map* m = new tkhip_map();
+    m->ctx = ctx;
+    m->cap = capacity;
+    m->k = k;
+    size_t c = (size_t)(capacity > 0 ? capacity : 1);
+    int rc = m->in_pos.ensure(c * 12);
+    if (!rc) rc = m->in_pow.ensure(c * 12);
+    if (!rc) rc = m->in_dir.ensure(c * 2);
+    if (!rc) rc = m->counters.ensure(64);
+    if (!rc) rc = upload_direction_tables(ctx);
+    if (rc) { map_destroy(m); return rc; }
+    *out = m;
+    return TKHIP_OK;
+}
+
+void map_destroy(tkhip_map* m) {
+    if (!m) return;
+    DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->node_axis,
+                      &m->clip_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
+                      &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters};
+    for (DevBuf* b : bufs) b->release();
+    delete m;
+}
+
+int map_set_photons_device(tkhip_map* m, const float* pos, const float* power, const uint16_t* dir, int64_t n) {
+    TK_REQUIRE(n >= 0 && n <= m->cap, TKHIP_E_LIMIT, "map_set_photons: %lld photons exceed capacity %lld", (long long)n,
+               (long long)m->cap);
+    hipStream_t s = m->ctx->stream;
+    if (n > 0) {
+        TK_HIP(hipMemcpyAsync(m->in_pos.p, pos, (size_t)n * 12, hipMemcpyDeviceToDevice, s));
+        TK_HIP(hipMemcpyAsync(m->in_pow.p, power, (size_t)n * 12, hipMemcpyDeviceToDevice, s));
+        TK_HIP(hipMemcpyAsync(m->in_dir.p, dir, (size_t)n * 2, hipMemcpyDeviceToDevice, s));
+    }
+    m->n = n;
+    m->built = false;
+    return TKHIP_OK;
+}
+
+int map_build(tkhip_map* m) {
+    tkhip_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    const int64_t n = m->n;
+    m->built = false;
+    if (n == 0) { m->nl = 0; m->depth = 0; m->built = true; return TKHIP_OK; }
+    int64_t want = (n + kLeafCap - 1) / kLeafCap;
+    int nl = 1, depth = 0;
+    while (nl < want) { nl <<= 1; ++depth; }
+    m->nl = nl;
+    m->depth = depth;
+    TK_TRY(m->pos4.ensure((size_t)n * 16));
+    TK_TRY(m->pow4.ensure((size_t)n * 16));
+    TK_TRY(m->node_box.ensure((size_t)nl * 2 * 32));
+    TK_TRY(m->node_axis.ensure((size_t)nl * 2 * 4));
+    TK_TRY(m->clip_box.ensure((size_t)nl * 2 * 24));
+    TK_TRY(m->idx_a.ensure((size_t)n * 4));
+    TK_TRY(m->idx_b.ensure((size_t)n * 4));
+    TK_TRY(m->key_a.ensure((size_t)n * 8));
+    TK_TRY(m->key_b.ensure((size_t)n * 8));
+    TK_TRY(m->root_box.ensure(64));
+    const float* pos = m->in_pos.as<float>();
+    uint32_t* idx = m->idx_a.as<uint32_t>();
+    uint32_t* idx_alt = m->idx_b.as<uint32_t>();
+    const int B = 256;
+    k_iota<<<divup(n, B), B, 0, s>>>(idx, n);
+    TK_LAUNCH_CHECK();
+    if (depth > 0) {
+        k_root_box_init<<<1, 64, 0, s>>>(m->root_box.as<uint32_t>());
+        k_root_box<<<std::min(divup(n, B), 1024), B, 0, s>>>(pos, n, m->root_box.as<uint32_t>());
+        k_root_finish<<<1, 64, 0, s>>>(m->root_box.as<uint32_t>(), m->clip_box.as<float>());
+        TK_LAUNCH_CHECK();
+        for (int level = 0; level < depth; ++level) {
+            const int nodes = 1 << level;
+            k_level_axis<<<divup(nodes, B), B, 0, s>>>(m->clip_box.as<float>(), m->node_axis.as<int32_t>(), level);
+            k_level_keys<<<divup(n, B), B, 0, s>>>(pos, idx, m->node_axis.as<int32_t>(), m->key_a.as<uint64_t>(), n, nl,
+                                                   depth, level);
+            TK_LAUNCH_CHECK();
+            TK_TRY(sort_pairs_u64(ctx, m->key_a.as<uint64_t>(), m->key_b.as<uint64_t>(), idx, idx_alt, (size_t)n,
+                                  32 + level));
+            std::swap(idx, idx_alt);
+            k_level_split<<<divup(nodes, B), B, 0, s>>>(pos, idx, m->clip_box.as<float>(), m->node_axis.as<int32_t>(), n,
+                                                        nl, depth, level);
+            TK_LAUNCH_CHECK();
+        }
+    }
+    k_permute<<<divup(n, B), B, 0, s>>>(pos, m->in_pow.as<float>(), m->in_dir.as<uint16_t>(), idx, m->pos4.as<float4>(),
+                                        m->pow4.as<float4>(), n);
+    k_leaf_boxes<<<divup(nl, B), B, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl);
+    for (int level = depth - 1; level >= 0; --level)
+        k_inner_boxes<<<divup(1 << level, B), B, 0, s>>>(m->node_box.as<float4>(), level);
+    TK_LAUNCH_CHECK();
+    if (idx != m->idx_a.as<uint32_t>()) std::swap(m->idx_a, m->idx_b);   // idx_a always holds the final order
+    // the root box orders the queries of later gathers along a Morton curve
+    float4 rb[2];
+    TK_HIP(hipMemcpyAsync(rb, m->node_box.as<float4>() + 2, sizeof(rb), hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    m->scene_min[0] = rb[0].x; m->scene_min[1] = rb[0].y; m->scene_min[2] = rb[0].z;
+    m->scene_max[0] = rb[0].w; m->scene_max[1] = rb[1].x; m->scene_max[2] = rb[1].y;
+    m->built = true;
+    return TKHIP_OK;
+}
+
+}  // namespace tkd
+
+tkd::MapView tkhip_map::view() const {
+    tkd::MapView v;
+    v.pos4 = pos4.as<float4>();
+    v.pow4 = pow4.as<float4>();
+    v.node_box = node_box.as<float4>();
+    v.dirtab = ctx->b_dirtab.as<float>();
+    v.n = (int32_t)n;
+    v.nl = nl;
+    v.depth = depth;
+    v.k = k;
+    return v;
+}
+
+namespace tkd {
+
+template <int EPL>
+static void launch_wave(tkhip_map* m, const QueryView& qv, const int32_t* list, const int32_t* list_count,
+                        int64_t nq, int64_t work_hint, const GatherOut& out) {
+    int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(work_hint, 4), 1), 256 * 16);
+    k_gather_wave<EPL><<<blocks, 256, 0, m->ctx->stream>>>(m->view(), qv, list, list_count, nq, out);
+}
+
+int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed) {
+    TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
+    if (nq == 0) return TKHIP_OK;
+    TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
+    tkhip_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
+    auto wave_all = [&](const int32_t* list, const int32_t* cnt, int64_t hint) {
+        if (epl == 2) launch_wave<2>(m, qv, list, cnt, nq, hint, out);
+        else if (epl == 4) launch_wave<4>(m, qv, list, cnt, nq, hint, out);
+        else launch_wave<8>(m, qv, list, cnt, nq, hint, out);
+    };
+    m->last_group_ms = 0.f;
+    if (mode == 1) {
+        wave_all(nullptr, nullptr, nq);
+        TK_LAUNCH_CHECK();
+        return TKHIP_OK;
+    }
+    TK_TRY(m->q_keys_a.ensure((size_t)nq * 4));
+    TK_TRY(m->q_keys_b.ensure((size_t)nq * 4));
+    TK_TRY(m->q_vals_a.ensure((size_t)nq * 4));
+    TK_TRY(m->q_order.ensure((size_t)nq * 4));
+    TK_TRY(m->overflow.ensure((size_t)nq * 4));
+    // Morton order inside the root box of the tree
+    F3 bmin{m->scene_min[0], m->scene_min[1], m->scene_min[2]};
+    float ex = m->scene_max[0] - m->scene_min[0], ey = m->scene_max[1] - m->scene_min[1],
+          ez = m->scene_max[2] - m->scene_min[2];
+    F3 binv{ex > 0 ? 1023.f / ex : 0.f, ey > 0 ? 1023.f / ey : 0.f, ez > 0 ? 1023.f / ez : 0.f};
+    k_query_morton<<<divup(nq, 256), 256, 0, s>>>(qv, nq, bmin, binv, m->q_keys_a.as<uint32_t>(), m->q_vals_a.as<uint32_t>());
+    TK_LAUNCH_CHECK();
+    TK_TRY(sort_pairs_u32(ctx, m->q_keys_a.as<uint32_t>(), m->q_keys_b.as<uint32_t>(), m->q_vals_a.as<uint32_t>(),
+                          m->q_order.as<uint32_t>(), (size_t)nq, 30));
+    int32_t* ocount = m->counters.as<int32_t>();
+    TK_HIP(hipMemsetAsync(ocount, 0, 4, s));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        TK_HIP(hipEventCreate(&e0));
+        TK_HIP(hipEventCreate(&e1));
+        TK_HIP(hipEventRecord(e0, s));
+    }
+    const int64_t groups = (nq + 63) / 64;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), 256 * 32);
+    k_gather_group<<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out, m->overflow.as<int32_t>(),
+                                          ocount);
+    TK_LAUNCH_CHECK();
+    if (timed) {
+        TK_HIP(hipEventRecord(e1, s));
+        TK_HIP(hipEventSynchronize(e1));
+        TK_HIP(hipEventElapsedTime(&m->last_group_ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    wave_all(m->overflow.as<int32_t>(), ocount, nq);
+    TK_LAUNCH_CHECK();
+    return TKHIP_OK;
+}
+
+__global__ void k_pack_store(const float* pos, const float* pow, const uint8_t* th, const uint8_t* ph, float* dpos,
+                             float* dpow, uint16_t* ddir, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int a = 0; a < 3; ++a) { dpos[3 * i + a] = pos[3 * i + a]; dpow[3 * i + a] = pow[3 * i + a]; }
+    ddir[i] = (uint16_t)th[i] | ((uint16_t)ph[i] << 8);
+}
+
+__global__ void k_pack_queries(const float* p, const float* n, const float* wo, const float* R, const float* r2,
+                               float4* q0, float4* q1, float4* q2, float4* q3, int64_t nq) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    F3 nn = ld3(n + 3 * i), w = ld3(wo + 3 * i);
+    q0[i] = make_float4(p[3 * i], p[3 * i + 1], p[3 * i + 2], r2[i]);
+    q1[i] = make_float4(nn.x, nn.y, nn.z, dot3(w, nn));
+    q2[i] = make_float4(1.f, 1.f, 1.f, __int_as_float(0));
+    q3[i] = make_float4(R[3 * i] * kInvPi, R[3 * i + 1] * kInvPi, R[3 * i + 2] * kInvPi, 0.f);
+}
+
+__global__ void k_pixel_update(int64_t n, float* flux, float* photons, float* radius2, const float* lindir,
+                               const int32_t* found, const float* r2ret) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pixel_update(&flux[3 * i], &flux[3 * i + 1], &flux[3 * i + 2], &photons[i], &radius2[i], ld3(lindir + 3 * i),
+                 found[i], r2ret[i]);
+}
+
+}  // namespace tkd
+
+// ------------------------------------------------------------------ C ABI
+using namespace tkd;
+
+extern "C" {
+
+int tkhip_map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
+    TK_REQUIRE(ctx && out, TKHIP_E_ARG, "tkhip_map_create: null argument");
+    TK_HIP(hipSetDevice(ctx->device));
+    return map_create(ctx, capacity, k, out);
+}
+
+void tkhip_map_destroy(tkhip_map* map) {
+    if (!map) return;
+    (void)hipSetDevice(map->ctx->device);
+    (void)hipStreamSynchronize(map->ctx->stream);
+    map_destroy(map);
+}
+
+int tkhip_map_store(tkhip_map* m, const float* pos, const float* power, const uint8_t* theta, const uint8_t* phi,
+                    int64_t n) {
+    TK_REQUIRE(m && (n == 0 || (pos && power && theta && phi)), TKHIP_E_ARG, "tkhip_map_store: null argument");
+    TK_REQUIRE(n >= 0 && m->n + n <= m->cap, TKHIP_E_LIMIT, "tkhip_map_store: %lld + %lld photons exceed capacity %lld",
+               (long long)m->n, (long long)n, (long long)m->cap);
+    if (n == 0) return TKHIP_OK;
+    tkhip_ctx* ctx = m->ctx;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TK_TRY(ctx->scratch_a.ensure((size_t)n * 12));
+    TK_TRY(ctx->scratch_b.ensure((size_t)n * 12));
+    TK_TRY(ctx->scratch_c.ensure((size_t)n * 2));
+    TK_HIP(hipMemcpyAsync(ctx->scratch_a.p, pos, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(ctx->scratch_b.p, power, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    uint8_t* dth = ctx->scratch_c.as<uint8_t>();
+    TK_HIP(hipMemcpyAsync(dth, theta, (size_t)n, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(dth + n, phi, (size_t)n, hipMemcpyHostToDevice, s));
+    k_pack_store<<<divup(n, 256), 256, 0, s>>>(ctx->scratch_a.as<float>(), ctx->scratch_b.as<float>(), dth, dth + n,
+                                               m->in_pos.as<float>() + 3 * m->n, m->in_pow.as<float>() + 3 * m->n,
+                                               m->in_dir.as<uint16_t>() + m->n, n);
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipStreamSynchronize(s));
+    m->n += n;
+    m->built = false;
+    return TKHIP_OK;
+}
+
+int tkhip_map_build(tkhip_map* m) {
+    TK_REQUIRE(m, TKHIP_E_ARG, "tkhip_map_build: null map");
+    TK_HIP(hipSetDevice(m->ctx->device));
+    TK_TRY(map_build(m));
+    TK_HIP(hipStreamSynchronize(m->ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_map_tree_info(tkhip_map* m, int32_t* n_leaves, int32_t* leaf_capacity, int32_t* depth, int32_t* perm) {
+    TK_REQUIRE(m && m->built, TKHIP_E_STATE, "tkhip_map_tree_info: map not built");
+    if (n_leaves) *n_leaves = m->nl;
+    if (leaf_capacity) *leaf_capacity = kLeafCap;
+    if (depth) *depth = m->depth;
+    if (perm && m->n > 0) {
+        TK_HIP(hipSetDevice(m->ctx->device));
+        TK_HIP(hipMemcpy(perm, m->idx_a.p, (size_t)m->n * 4, hipMemcpyDeviceToHost));
+    }
+    return TKHIP_OK;
+}
+
+int tkhip_map_gather(tkhip_map* m, int64_t nq, const float* p, const float* n, const float* wo, const float* R,
+                     const float* radius2, float* flux, int32_t* found, float* radius2_out, int32_t* idx, int mode) {
+    TK_REQUIRE(m && (nq == 0 || (p && n && wo && R && radius2)), TKHIP_E_ARG, "tkhip_map_gather: null argument");
+    TK_REQUIRE(mode == 0 || mode == 1, TKHIP_E_ARG, "tkhip_map_gather: mode must be 0 or 1");
+    TK_REQUIRE(m->built, TKHIP_E_STATE, "tkhip_map_gather: call tkhip_map_build first");
+    if (nq == 0) return TKHIP_OK;
+    tkhip_ctx* ctx = m->ctx;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t q = (size_t)nq;
+    DevBuf in, qb, ob;
+    int rc = in.ensure(q * 52);
+    if (!rc) rc = qb.ensure(q * 64);
+    if (!rc) rc = ob.ensure(q * (12 + 4 + 4) + (idx ? q * (size_t)m->k * 4 : 0) + 64);
+    auto cleanup = [&]() { in.release(); qb.release(); ob.release(); };
+    if (rc) { cleanup(); return rc; }
+    float* d_in = in.as<float>();
+    float *dp = d_in, *dn = d_in + 3 * q, *dw = d_in + 6 * q, *dR = d_in + 9 * q, *dr2 = d_in + 12 * q;
+    hipError_t e = hipMemcpyAsync(dp, p, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dn, n, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dw, wo, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dR, R, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr2, radius2, q * 4, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { set_error("tkhip_map_gather: upload failed: %s", hipGetErrorString(e)); cleanup(); return TKHIP_E_HIP; }
+    float4* q4 = qb.as<float4>();
+    QueryView qv{q4, q4 + q, q4 + 2 * q, q4 + 3 * q};
+    k_pack_queries<<<divup(nq, 256), 256, 0, s>>>(dp, dn, dw, dR, dr2, q4, q4 + q, q4 + 2 * q, q4 + 3 * q, nq);
+    GatherOut out{};
+    char* o = ob.as<char>();
+    out.flux = (float*)o;
+    out.found = (int32_t*)(o + q * 12);
+    out.r2out = (float*)(o + q * 16);
+    out.idx = idx ? (int32_t*)(o + q * 20) : nullptr;
+    if (idx) (void)hipMemsetAsync(out.idx, 0xff, q * (size_t)m->k * 4, s);
+    rc = map_gather_device(m, nq, qv, out, mode, false);
+    if (!rc) {
+        e = hipStreamSynchronize(s);
+        if (e == hipSuccess && flux) e = hipMemcpy(flux, out.flux, q * 12, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && found) e = hipMemcpy(found, out.found, q * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && radius2_out) e = hipMemcpy(radius2_out, out.r2out, q * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && idx) e = hipMemcpy(idx, out.idx, q * (size_t)m->k * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("tkhip_map_gather: %s", hipGetErrorString(e)); rc = TKHIP_E_HIP; }
+    }
+    (void)hipStreamSynchronize(s);
+    cleanup();
+    return rc;
+}
+
+int tkhip_pixel_update(tkhip_ctx* ctx, int64_t n, float* flux, float* photons, float* radius2, const float* lindir,
+                       const int32_t* found, const float* radius2_ret) {
+    TK_REQUIRE(ctx && (n == 0 || (flux && photons && radius2 && lindir && found && radius2_ret)), TKHIP_E_ARG,
+               "tkhip_pixel_update: null argument");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    const size_t q = (size_t)n;
+    DevBuf b;
+    TK_TRY(b.ensure(q * (12 + 4 + 4 + 12 + 4 + 4)));
+    float* d = b.as<float>();
+    float *dflux = d, *dph = d + 3 * q, *dr2 = d + 4 * q, *dl = d + 5 * q, *drr = d + 8 * q;
+    int32_t* dfound = (int32_t*)(d + 9 * q);
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemcpyAsync(dflux, flux, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dph, photons, q * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr2, radius2, q * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dl, lindir, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(drr, radius2_ret, q * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dfound, found, q * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        k_pixel_update<<<divup(n, 256), 256, 0, s>>>(n, dflux, dph, dr2, dl, dfound, drr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(flux, dflux, q * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(photons, dph, q * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(radius2, dr2, q * 4, hipMemcpyDeviceToHost);
+    b.release();
+    if (e != hipSuccess) { set_error("tkhip_pixel_update: %s", hipGetErrorString(e)); return TKHIP_E_HIP; }
+    return TKHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,862 @@
+// sppm_render.hip — one SPPM iteration on the device: photon passes, map
+// builds, camera pass with gathers, resolve.
+//
+// Shape of the work (one wavefront stage per bounce, queues compacted between
+// bounces; every stage traces its own rays with the LDS-stack traversal):
+//   photon pass : k_photon_emit -> k_photon_bounce x depth -> scan -> k_photon_scatter
+//                 (tracePhoton / traceCausticPhoton, src/tracer/TkSppmTracer.cpp:104-217)
+//   camera pass : k_camera_gen -> k_camera_bounce x depth -> gathers
+//                 (traceTile, src/tracer/TkSppmTracer.cpp:290-374)
+//   resolve     : k_resolve (src/tracer/TkSppmTracer.cpp:514-529)
+//
+// "Emit until the map holds N photons" (src/tracer/TkSppmTracer.cpp:411-421) is
+// sequential in the CPU code.  Here light paths are traced in batches, each
+// path keeps its photons in a private staging slot, and a prefix scan in path
+// order cuts the batch where the map is full: the map holds the first N
+// photons in path order and the shoot counter is the index of the path that
+// filled it, which is what a single CPU thread produces.
+#include <algorithm>
+
+#include "photon_map.h"
+#include "tk_bvh_device.h"
+
+namespace tkd {
+
+enum { C_QA = 0, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */ };
+
+struct SppmState {
+    TkSppmParam prm{};
+    int num_recurse = 1, xs = 1, ys = 1, max_depth = 20;
+    float rr = 0.8f;
+    uint32_t seed = 0;
+    int rank = 0, world = 1;
+    tkhip_map* map[2] = {nullptr, nullptr};
+    int64_t quota[2] = {0, 0};
+    DevBuf loc_pos[2], loc_pow[2], loc_dir[2];
+    int64_t n_loc[2] = {0, 0}, last_shot[2] = {0, 0}, local_shot[2] = {0, 0}, shoot[2] = {0, 0};
+    int64_t stored_c = 0;
+    double yield[2] = {2.0, 0.05};
+    // pixels
+    DevBuf planes, rows;
+    int64_t n_pixels = 0;
+    int n_rows = 0;
+    int64_t n_slots = 0;
+    // path state and queues
+    DevBuf st_o, st_d, st_w, queue_a, queue_b, counters;
+    DevBuf stage_pos, stage_pow, rec_count, rec_offset;
+    DevBuf qbuf[2];
+    int64_t path_cap = 0;
+};
+
+struct PathState {
+    float4* o;   // origin xyz; photon: u5 | camera: unused
+    float4* d;   // direction xyz; photon: u6 | camera: unused
+    float4* w;   // photon: power rgb, flags | camera: throughput rgb, flags (bit0 only-specular-so-far, bits 1.. sampler dim)
+};
+
+struct PhotonArgs {
+    DScene sc;
+    PathState st;
+    int32_t* rec_count;
+    float4* stage_pos;   // xyz + direction bits
+    float4* stage_pow;   // rgb
+    int64_t m0;          // local index of the first path of the batch
+    int64_t hoff;        // Halton offset (caustic paths: + paths shot for the global map)
+    int world, rank;
+    uint32_t seed;
+    float rr;
+    int slots;           // staging records per path
+    int depth;
+};
+
+TKD uint64_t halton_index(const PhotonArgs& a, int slot) {
+    return (uint64_t)(a.m0 + slot + a.hoff) * (uint64_t)a.world + (uint64_t)a.rank;
+}
+
+// Light choice, AreaLight::sample_Le and the initial power of a light path
+// (src/tracer/TkSppmTracer.cpp:106-122, src/Light.cpp:41-75,
+// src/Triangle.cpp:190-197).
+template <int KIND>
+__global__ void __launch_bounds__(256) k_photon_emit(PhotonArgs a, int64_t B, int32_t* queue, int32_t* counters) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool alive = false;
+    if (i < B) {
+        const DScene& sc = a.sc;
+        uint64_t H = halton_index(a, (int)i);
+        a.rec_count[i] = 0;
+        int nl = sc.n_lights;
+        if (nl > 0) {
+            int li = (int)(radical_inverse(0, H) * nl);
+            li = li > nl - 1 ? nl - 1 : li;
+            float pdf = 1.0f / nl;
+            float u0x = radical_inverse(1, H), u0y = radical_inverse(2, H);
+            float u1x = radical_inverse(3, H), u1y = radical_inverse(4, H);
+            float ubx = radical_inverse(5, H), uby = radical_inverse(6, H);
+            const DLight L = sc.lights[li];
+            float upick = photon_rng(a.seed, H, KIND, 0, 0);
+            float pd, tmp;
+            int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, upick, &pd);
+            LightPoint lp = tri_sample(sc, L.tri_first + idx, u0x, u0y, &tmp);
+            float pos_pdf = pd * tmp, dir_pdf;
+            F3 w;
+            if (L.two_sided) {
+                float ux = u1x;
+                if (ux < 0.5f) { ux = sse_min(ux * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); }
+                else { ux = sse_min((ux - 0.5f) * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); w.z *= -1; }
+                dir_pdf = 0.5f * (fabsf(w.z) * kInvPi);
+            } else {
+                w = cosine_hemisphere(u1x, u1y);
+                dir_pdf = w.z * kInvPi;
+            }
+            F3 v1, v2;
+            coordinate_system(lp.n, &v1, &v2);
+            w = add3(add3(scale3(v1, w.x), scale3(v2, w.y)), scale3(lp.n, w.z));
+            F3 o = offset_ray_origin(lp.p, lp.perr, lp.n, w);
+            F3 Le = light_L(L, lp.n, w);
+            if (!(pos_pdf == 0 || dir_pdf == 0)) {
+                F3 power = divs3(scale3(Le, absdot3(w, lp.n)), pos_pdf * dir_pdf * pdf);
+                a.st.o[i] = make_float4(o.x, o.y, o.z, ubx);
+                a.st.d[i] = make_float4(w.x, w.y, w.z, uby);
+                a.st.w[i] = make_float4(power.x, power.y, power.z, __int_as_float(0));
+                alive = true;
+            }
+        }
+    }
+    int dst = wave_append(&counters[C_QA], alive);
+    if (alive) queue[dst] = (int32_t)i;
+}
+
+// One bounce of every live light path: closest hit, photon store at diffuse
+// surfaces, Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156
+// for the global map, :179-216 for the caustic map).
+template <int KIND>
+__global__ void __launch_bounds__(256) k_photon_bounce(PhotonArgs a, int bounce, const int32_t* qin,
+                                                       const int32_t* count_in, int32_t* qout, int32_t* count_out,
+                                                       unsigned long long* rays) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int n = *count_in;
+    bool go_on = false;
+    int slot = 0;
+    if (j < n) {
+        slot = qin[j];
+        const DScene& sc = a.sc;
+        float4 so = a.st.o[slot], sd = a.st.d[slot], sw = a.st.w[slot];
+        F3 o = mk3(so.x, so.y, so.z), d = mk3(sd.x, sd.y, sd.z), power = mk3(sw.x, sw.y, sw.z);
+        int flags = __float_as_int(sw.w);
+        Hit h = trace_ray<false>(sc, o, d, 1.7976931348623157e308, stk);
+        if (h.prim >= 0) {
+            SurfacePoint sp = surface_at(sc, h, o, d);
+            F3 wo = neg3(d);
+            const TkMaterial m = sc.mats[sp.mat];
+            bool diffuse = m.type == TK_DIFFUSE;
+            bool stop = false;
+            if (KIND == 0) {
+                if (diffuse) {
+                    int c = a.rec_count[slot];
+                    int64_t at = (int64_t)slot * a.slots + c;
+                    a.stage_pos[at] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
+                    a.stage_pow[at] = make_float4(power.x, power.y, power.z, 0.f);
+                    a.rec_count[slot] = c + 1;
+                }
+            } else {
+                if (!diffuse) flags |= 1;
+                if (diffuse) {
+                    if (flags & 1) {
+                        a.stage_pos[slot] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
+                        a.stage_pow[slot] = make_float4(power.x, power.y, power.z, 0.f);
+                        a.rec_count[slot] = 1;
+                    }
+                    stop = true;
+                }
+            }
+            uint64_t H = halton_index(a, slot);
+            if (!stop && !(photon_rng(a.seed, H, KIND, bounce, 1) > a.rr)) {
+                F3 wi;
+                float pdf;
+                F3 f = mat_sample_f(m, true, wo, &wi, sp.n, so.w, sd.w, &pdf);
+                if (!(pdf == 0 || isblack(f))) {
+                    power = divs3(scale3(mul3(power, f), absdot3(wi, sp.n)), pdf * a.rr);
+                    F3 no = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
+                    if (bounce + 1 < a.depth) {
+                        a.st.o[slot] = make_float4(no.x, no.y, no.z, so.w);
+                        a.st.d[slot] = make_float4(wi.x, wi.y, wi.z, sd.w);
+                        a.st.w[slot] = make_float4(power.x, power.y, power.z, __int_as_float(flags));
+                        go_on = true;
+                    }
+                }
+            }
+        }
+    }
+    int dst = wave_append(count_out, go_on);
+    if (go_on) qout[dst] = slot;
+    unsigned long long traced = __ballot(j < n);
+    if ((threadIdx.x & 63) == 0 && traced) atomicAdd(rays, (unsigned long long)__popcll(traced));
+}
+
+// Appends the staged photons of the batch in path order behind the `base`
+// photons already stored, up to `quota`; reports how many photons the batch
+// produced and which path filled the map.
+__global__ void k_photon_scatter(const int32_t* rec_count, const int32_t* rec_offset, const float4* stage_pos,
+                                 const float4* stage_pow, int slots, int64_t B, int64_t base, int64_t quota,
+                                 float* out_pos, float* out_pow, uint16_t* out_dir, int32_t* counters) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    int c = rec_count[i];
+    int64_t off = rec_offset[i];
+    int64_t need = quota - base;
+    for (int r = 0; r < c; ++r) {
+        int64_t g = off + r;
+        if (g >= need) break;
+        float4 p = stage_pos[i * slots + r], w = stage_pow[i * slots + r];
+        int64_t at = base + g;
+        out_pos[3 * at] = p.x; out_pos[3 * at + 1] = p.y; out_pos[3 * at + 2] = p.z;
+        out_pow[3 * at] = w.x; out_pow[3 * at + 1] = w.y; out_pow[3 * at + 2] = w.z;
+        out_dir[at] = (uint16_t)__float_as_uint(p.w);
+    }
+    if (off < need && off + c >= need) counters[C_USED] = (int32_t)(i + 1);
+    if (i == B - 1) counters[C_TOTAL] = (int32_t)(off + c);
+}
+
+// ------------------------------------------------------------ camera pass
+struct CameraArgs {
+    DScene sc;
+    DCamera cam;
+    PathState st;
+    const int32_t* rows;
+    float* planes;
+    int64_t n_pixels;
+    int iter, spp, xs, ys, depth;
+    uint32_t seed;
+    int caustic_stored;
+    float4* gq;          // global queries: 4 arrays of capacity n_slots, back to back
+    float4* cq;          // caustic queries
+    int64_t qcap;
+};
+
+TKD Sampler make_sampler(const CameraArgs& a, int x, int y, int dim) {
+    Sampler s;
+    s.px = x; s.py = y; s.sample_idx = a.iter; s.spp = a.spp; s.xs = a.xs; s.ys = a.ys; s.dim = dim;
+    s.rng_seed = a.seed; s.rng_pixel = (uint32_t)(x + y * a.cam.w); s.rng_iter = (uint32_t)a.iter;
+    return s;
+}
+
+// src/tracer/TkSppmTracer.cpp:296-304
+__global__ void __launch_bounds__(256) k_camera_gen(CameraArgs a, int64_t n_slots, int32_t* queue) {
+    int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    int W = a.cam.w;
+    int y = a.rows[slot / W], x = (int)(slot % W);
+    Sampler sm = make_sampler(a, x, y, 0);
+    float cx, cy, lx, ly;
+    sampler_get2d(sm, &cx, &cy);
+    cx = cx + (float)x; cy = cy + (float)y;
+    sampler_get2d(sm, &lx, &ly);   // lens sample: drawn and unused with a pinhole camera
+    F3 o, d;
+    camera_ray(a.cam, cx, cy, &o, &d);
+    a.st.o[slot] = make_float4(o.x, o.y, o.z, 0.f);
+    a.st.d[slot] = make_float4(d.x, d.y, d.z, 0.f);
+    a.st.w[slot] = make_float4(1.f, 1.f, 1.f, __int_as_float(1 | (sm.dim << 1)));
+    queue[slot] = (int32_t)slot;
+}
+
+TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp, F3 coef, const TkMaterial& m,
+                    float radius2, int pixel) {
+    qbase[dst] = make_float4(sp.p.x, sp.p.y, sp.p.z, radius2);
+    qbase[qcap + dst] = make_float4(sp.n.x, sp.n.y, sp.n.z, dot3(sp.wo, sp.n));
+    qbase[2 * qcap + dst] = make_float4(coef.x, coef.y, coef.z, __int_as_float(pixel));
+    qbase[3 * qcap + dst] = make_float4(m.R[0] * kInvPi, m.R[1] * kInvPi, m.R[2] * kInvPi, 0.f);
+}
+
+// One bounce of every live camera path (loop body of traceTile,
+// src/tracer/TkSppmTracer.cpp:306-371, with Scene::uniformSampleOneLight,
+// src/core/Scene.cpp:43-61, inlined).
+__global__ void __launch_bounds__(256) k_camera_bounce(CameraArgs a, int bounce, const int32_t* qin,
+                                                       const int32_t* count_in, int32_t* qout, int32_t* counters,
+                                                       int out_counter) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int n = *count_in;
+    bool go_on = false, want_gq = false, want_cq = false;
+    int slot = 0, pixel = 0, nrays = 0;
+    SurfacePoint sp{};
+    F3 coef = mk3(0, 0, 0);
+    TkMaterial m{};
+    const DScene& sc = a.sc;
+    if (j < n) {
+        slot = qin[j];
+        const int W = a.cam.w;
+        const int y = a.rows[slot / W], x = slot % W;
+        pixel = x + y * W;
+        float4 so = a.st.o[slot], sd = a.st.d[slot], sw = a.st.w[slot];
+        F3 o = mk3(so.x, so.y, so.z), d = mk3(sd.x, sd.y, sd.z);
+        coef = mk3(sw.x, sw.y, sw.z);
+        int flags = __float_as_int(sw.w);
+        bool has_glossy = flags & 1;
+        Sampler sm = make_sampler(a, x, y, flags >> 1);
+        Hit h = trace_ray<false>(sc, o, d, 1.7976931348623157e308, stk);
+        ++nrays;
+        if (h.prim >= 0) {
+            sp = surface_at(sc, h, o, d);
+            m = sc.mats[sp.mat];
+            const bool diffuse = m.type == TK_DIFFUSE;
+            const F3 wo = neg3(d);
+            F3 Ld = mk3(0, 0, 0);
+            if (has_glossy && sp.light >= 0) Ld = add3(Ld, mul3(coef, light_L(sc.lights[sp.light], sp.n, wo)));
+            if ((has_glossy || !diffuse) && sc.n_lights > 0) {
+                // uniformSampleOneLight: the sampler dimensions advance for every material
+                int nl = sc.n_lights;
+                int li = (int)(sampler_get1d(sm) * nl);
+                li = li > nl - 1 ? nl - 1 : li;
+                float pdf_choice = 1.0f / nl;
+                float ulx, uly;
+                sampler_get2d(sm, &ulx, &uly);
+                float u0 = sampler_get1d(sm);
+                if (diffuse) {   // f() of mirror and glass is black: nothing to add, no shadow ray needed
+                    const DLight L = sc.lights[li];
+                    float pd, tmp;
+                    int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, u0, &pd);
+                    LightPoint lp = tri_sample(sc, L.tri_first + idx, ulx, uly, &tmp);
+                    F3 wv = sub3(lp.p, sp.p);
+                    float dist2 = dot3(wv, wv);
+                    if (dist2 == 0) tmp = 0;
+                    else { F3 wn = normalize3(wv); tmp *= dist2 / absdot3(lp.n, neg3(wn)); }
+                    float pdf_light = pd * tmp;
+                    if (!(pdf_light == 0 || dist2 == 0)) {
+                        F3 ws = normalize3(wv);
+                        F3 Li = light_L(L, lp.n, neg3(ws));
+                        if (!isblack(Li)) {
+                            // Intersection::spawnRayTo(other), src/Intersection.hpp:40-48
+                            F3 so2 = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
+                            F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(so2, lp.p));
+                            Hit sh = trace_ray<true>(sc, so2, sub3(target, so2), (double)kOneMinusEps, stk);
+                            ++nrays;
+                            if (sh.prim < 0) {
+                                F3 f = mat_f(m, sp.wo, ws, sp.n);
+                                Ld = add3(Ld, mul3(coef, divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice)));
+                            }
+                        }
+                    }
+                }
+            }
+            if (!isblack(Ld)) {
+                a.planes[pixel] += Ld.x;
+                a.planes[a.n_pixels + pixel] += Ld.y;
+                a.planes[2 * a.n_pixels + pixel] += Ld.z;
+            }
+            bool end_path = false;
+            if (diffuse) {
+                if (has_glossy && a.caustic_stored > 0) want_cq = true;
+                if (!has_glossy) { want_gq = true; end_path = true; }
+            }
+            if (!end_path) {
+                has_glossy = has_glossy && !diffuse;
+                float ux, uy;
+                sampler_get2d(sm, &ux, &uy);
+                F3 wi;
+                float pdf;
+                F3 f = mat_sample_f(m, false, wo, &wi, sp.n, ux, uy, &pdf);
+                if (!(isblack(f) || pdf == 0) && bounce + 1 < a.depth) {
+                    F3 ncoef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
+                    F3 no = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
+                    a.st.o[slot] = make_float4(no.x, no.y, no.z, 0.f);
+                    a.st.d[slot] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                    a.st.w[slot] = make_float4(ncoef.x, ncoef.y, ncoef.z, __int_as_float((has_glossy ? 1 : 0) | (sm.dim << 1)));
+                    go_on = true;
+                }
+            }
+        }
+    }
+    int dc = wave_append(&counters[C_NCQ], want_cq);
+    if (want_cq) emit_query(a.cq, a.qcap, dc, sp, coef, m, a.planes[11 * a.n_pixels + pixel], pixel);
+    int dg = wave_append(&counters[C_NGQ], want_gq);
+    if (want_gq) emit_query(a.gq, a.qcap, dg, sp, coef, m, a.planes[12 * a.n_pixels + pixel], pixel);
+    int dst = wave_append(&counters[out_counter], go_on);
+    if (go_on) qout[dst] = slot;
+    float wr = (float)nrays;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
+    if ((threadIdx.x & 63) == 0 && wr > 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
+}
+
+// Final colour + gamma + RGB8, rows bottom-up (src/tracer/TkSppmTracer.cpp:514-529)
+__global__ void k_resolve(const float* planes, int64_t np, int W, int H, int num_recurse, float shoot_g,
+                          float shoot_c, int caustic_stored, uint8_t* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    int x = (int)(i % W), y = (int)(i / W);
+    float cr2 = planes[11 * np + i], gr2 = planes[12 * np + i];
+    for (int ch = 0; ch < 3; ++ch) {
+        float v = planes[ch * np + i] / (float)num_recurse;
+        if (caustic_stored > 0) v = v + planes[(3 + ch) * np + i] / (kPi * cr2 * shoot_c);
+        else v = v + 0.f;
+        v = v + planes[(6 + ch) * np + i] / (kPi * gr2 * shoot_g);
+        float cl = sse_max(sse_min(v, 1.0f), 0.0f);
+        out[((int64_t)(H - 1 - y) * W + x) * 3 + ch] = (uint8_t)(255 * powf(cl, 0.6f));
+    }
+}
+
+__global__ void k_init_planes(float* planes, int64_t np, float radius2) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    for (int pl = 0; pl < 11; ++pl) planes[pl * np + i] = 0.f;
+    planes[11 * np + i] = radius2;
+    planes[12 * np + i] = radius2;
+}
+
+__global__ void k_planes_to_aos(const float* planes, int64_t np, float* aos) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    for (int pl = 0; pl < 13; ++pl) aos[13 * i + pl] = planes[pl * np + i];
+}
+
+__global__ void k_unpack_dir(const uint16_t* dir, uint8_t* th, uint8_t* ph, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    th[i] = (uint8_t)(dir[i] & 255u);
+    ph[i] = (uint8_t)(dir[i] >> 8);
+}
+
+// ----------------------------------------------------------------- host side
+void destroy_sppm(tkhip_ctx* ctx) {
+    SppmState* s = ctx->sppm;
+    if (!s) return;
+    for (int w = 0; w < 2; ++w) {
+        if (s->map[w]) map_destroy(s->map[w]);
+        s->loc_pos[w].release(); s->loc_pow[w].release(); s->loc_dir[w].release(); s->qbuf[w].release();
+    }
+    DevBuf* bufs[] = {&s->planes, &s->rows, &s->st_o, &s->st_d, &s->st_w, &s->queue_a, &s->queue_b, &s->counters,
+                      &s->stage_pos, &s->stage_pow, &s->rec_count, &s->rec_offset};
+    for (DevBuf* b : bufs) b->release();
+    delete s;
+    ctx->sppm = nullptr;
+}
+
+static int ensure_paths(SppmState* s, int64_t n) {
+    TK_TRY(s->st_o.ensure((size_t)n * 16));
+    TK_TRY(s->st_d.ensure((size_t)n * 16));
+    TK_TRY(s->st_w.ensure((size_t)n * 16));
+    TK_TRY(s->queue_a.ensure((size_t)n * 4));
+    TK_TRY(s->queue_b.ensure((size_t)n * 4));
+    return TKHIP_OK;
+}
+
+struct Timer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s;
+    bool on;
+    Timer(hipStream_t st, bool enable) : s(st), on(enable) {
+        if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s); }
+    }
+    float stop() {
+        float ms = 0.f;
+        if (on) { (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); }
+        return ms;
+    }
+    ~Timer() { if (on) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } }
+};
+
+template <int KIND>
+static int photon_pass_kind(tkhip_ctx* ctx, TkIterStats* st) {
+    SppmState* s = ctx->sppm;
+    hipStream_t stream = ctx->stream;
+    const int64_t quota = s->quota[KIND];
+    int64_t stored = 0, shot = 0;
+    const int slots = KIND == 0 ? s->max_depth : 1;
+    const int depth = KIND == 0 ? s->max_depth : 64;
+    int32_t* counters = s->counters.as<int32_t>();
+    const int64_t emitted_cap = KIND == 0 ? (int64_t)1 << 40 : quota * 4000 + 100000;
+    int32_t host_counters[16];
+    while (stored < quota && shot < emitted_cap) {
+        int64_t need = quota - stored;
+        int64_t B = (int64_t)((double)need / s->yield[KIND] * 1.02) + 256;
+        B = std::min<int64_t>(B, (int64_t)1 << 24);
+        TK_TRY(ensure_paths(s, B));
+        TK_TRY(s->stage_pos.ensure((size_t)B * slots * 16));
+        TK_TRY(s->stage_pow.ensure((size_t)B * slots * 16));
+        TK_TRY(s->rec_count.ensure((size_t)B * 4));
+        TK_TRY(s->rec_offset.ensure((size_t)B * 4));
+        PhotonArgs a;
+        a.sc = ctx->scene;
+        a.st = PathState{s->st_o.as<float4>(), s->st_d.as<float4>(), s->st_w.as<float4>()};
+        a.rec_count = s->rec_count.as<int32_t>();
+        a.stage_pos = s->stage_pos.as<float4>();
+        a.stage_pow = s->stage_pow.as<float4>();
+        a.m0 = s->local_shot[KIND] + shot;
+        a.hoff = KIND == 0 ? 0 : s->local_shot[0];
+        a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
+        TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
+        int32_t* qa = s->queue_a.as<int32_t>();
+        int32_t* qb = s->queue_b.as<int32_t>();
+        const int grid = divup(B, 256);
+        k_photon_emit<KIND><<<grid, 256, 0, stream>>>(a, B, qa, counters);
+        TK_LAUNCH_CHECK();
+        int64_t live_bound = B;
+        int ca = C_QA, cb = C_QB;
+        for (int b = 0; b < depth; ++b) {
+            TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
+            k_photon_bounce<KIND><<<divup(live_bound, 256), 256, 0, stream>>>(
+                a, b, qa, &counters[ca], qb, &counters[cb], reinterpret_cast<unsigned long long*>(&counters[C_RAYS]));
+            TK_LAUNCH_CHECK();
+            std::swap(qa, qb);
+            std::swap(ca, cb);
+            if (b == 1 || b == 3 || b == 7 || b == 15 || b == 31) {
+                // shrink the launch to the live paths now and then, and stop early when none is left
+                int32_t live = 0;
+                TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
+                TK_HIP(hipStreamSynchronize(stream));
+                if (live == 0) break;
+                live_bound = live;
+            }
+        }
+        TK_TRY(exclusive_scan_i32(ctx, s->rec_count.as<int32_t>(), s->rec_offset.as<int32_t>(), (size_t)B));
+        k_photon_scatter<<<grid, 256, 0, stream>>>(s->rec_count.as<int32_t>(), s->rec_offset.as<int32_t>(),
+                                                   s->stage_pos.as<float4>(), s->stage_pow.as<float4>(), slots, B, stored,
+                                                   quota, s->loc_pos[KIND].as<float>(), s->loc_pow[KIND].as<float>(),
+                                                   s->loc_dir[KIND].as<uint16_t>(), counters);
+        TK_LAUNCH_CHECK();
+        TK_HIP(hipMemcpyAsync(host_counters, counters, 6 * 4, hipMemcpyDeviceToHost, stream));
+        TK_HIP(hipStreamSynchronize(stream));
+        int64_t total = host_counters[C_TOTAL];
+        int64_t got = std::min<int64_t>(total, need);
+        int64_t used = total >= need ? host_counters[C_USED] : B;
+        stored += got;
+        shot += used;
+        if (used > 0 && got > 0) s->yield[KIND] = 0.5 * s->yield[KIND] + 0.5 * ((double)got / (double)used);
+        else if (got == 0) s->yield[KIND] *= 0.25;
+        s->yield[KIND] = std::max(s->yield[KIND], 1e-4);
+    }
+    s->n_loc[KIND] = stored;
+    s->last_shot[KIND] = shot;
+    s->local_shot[KIND] += shot;
+    (void)st;
+    return TKHIP_OK;
+}
+
+static int read_u64_counter(tkhip_ctx* ctx, int at, bool reset, int64_t* out) {
+    SppmState* s = ctx->sppm;
+    unsigned long long v = 0;
+    int32_t* c = s->counters.as<int32_t>();
+    TK_HIP(hipMemcpyAsync(&v, &c[at], 8, hipMemcpyDeviceToHost, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    if (reset) TK_HIP(hipMemsetAsync(&c[at], 0, 8, ctx->stream));
+    *out = (int64_t)v;
+    return TKHIP_OK;
+}
+
+static int install_map(tkhip_ctx* ctx, int which, const float* pos, const float* pow, const uint16_t* dir, int64_t n,
+                       int64_t shot_total) {
+    SppmState* s = ctx->sppm;
+    TK_TRY(map_set_photons_device(s->map[which], pos, pow, dir, n));
+    s->shoot[which] += shot_total;
+    if (which == 1) s->stored_c = n;
+    return TKHIP_OK;
+}
+
+}  // namespace tkd
+
+using namespace tkd;
+
+#define TK_CTX_SPPM(ctx, fn)                                                             \
+    TK_REQUIRE((ctx) != nullptr, TKHIP_E_ARG, fn ": null context");                      \
+    TK_REQUIRE((ctx)->sppm != nullptr, TKHIP_E_STATE, fn ": call tkhip_sppm_begin first"); \
+    TK_HIP(hipSetDevice((ctx)->device))
+
+extern "C" {
+
+int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, float rr, uint64_t seed, int rank,
+                     int world) {
+    TK_REQUIRE(ctx && param, TKHIP_E_ARG, "tkhip_sppm_begin: null argument");
+    TK_REQUIRE(ctx->has_scene && ctx->has_camera, TKHIP_E_STATE, "tkhip_sppm_begin: set the scene and the camera first");
+    TK_REQUIRE(world >= 1 && rank >= 0 && rank < world, TKHIP_E_ARG, "tkhip_sppm_begin: bad rank %d / world %d", rank, world);
+    TK_REQUIRE(max_depth >= 1 && max_depth <= 64, TKHIP_E_LIMIT, "tkhip_sppm_begin: depth %d outside 1..64", max_depth);
+    TK_REQUIRE(param->globalSize >= 1 && param->causticSize >= 0, TKHIP_E_ARG, "tkhip_sppm_begin: bad photon map sizes");
+    TK_REQUIRE(param->numRecurse >= 1, TKHIP_E_ARG, "tkhip_sppm_begin: recurse must be >= 1");
+    TK_HIP(hipSetDevice(ctx->device));
+    destroy_sppm(ctx);
+    SppmState* s = new SppmState();
+    ctx->sppm = s;
+    s->prm = *param;
+    s->max_depth = max_depth; s->rr = rr; s->seed = (uint32_t)seed; s->rank = rank; s->world = world;
+    int x = 0, y = 0;
+    while (++x * ++y < param->numRecurse) {}   // src/tracer/TkSppmTracer.cpp:18-21
+    s->num_recurse = x * y; s->xs = x; s->ys = y;
+    int rc = map_create(ctx, param->globalSize, param->globalSample, &s->map[0]);
+    if (!rc) rc = map_create(ctx, std::max(param->causticSize, 1), param->causticSample, &s->map[1]);
+    if (rc) { destroy_sppm(ctx); return rc; }
+    s->quota[0] = param->globalSize / world + (rank < param->globalSize % world ? 1 : 0);
+    s->quota[1] = param->causticSize / world + (rank < param->causticSize % world ? 1 : 0);
+    for (int w = 0; w < 2 && !rc; ++w) {
+        size_t c = (size_t)std::max<int64_t>(s->quota[w], 1);
+        rc = s->loc_pos[w].ensure(c * 12);
+        if (!rc) rc = s->loc_pow[w].ensure(c * 12);
+        if (!rc) rc = s->loc_dir[w].ensure(c * 2);
+    }
+    const int W = ctx->cam.w, H = ctx->cam.h;
+    s->n_pixels = (int64_t)W * H;
+    std::vector<int32_t> rows;
+    for (int yy = 0; yy < H; ++yy)
+        if ((yy / 8) % world == rank) rows.push_back(yy);
+    s->n_rows = (int)rows.size();
+    s->n_slots = (int64_t)s->n_rows * W;
+    if (!rc) rc = s->planes.ensure((size_t)s->n_pixels * 13 * 4);
+    if (!rc) rc = s->rows.ensure(std::max<size_t>(rows.size(), 1) * 4);
+    if (!rc) rc = s->counters.ensure(64);
+    if (!rc) rc = ensure_paths(s, std::max<int64_t>(s->n_slots, 1));
+    for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
+    if (rc) { destroy_sppm(ctx); return rc; }
+    if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    TK_HIP(hipMemsetAsync(s->counters.p, 0, 64, ctx->stream));
+    k_init_planes<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, param->radius2);
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_photon_pass");
+    (void)iter;
+    SppmState* s = ctx->sppm;
+    Timer tm(ctx->stream, st != nullptr);
+    TK_HIP(hipMemsetAsync(&s->counters.as<int32_t>()[C_RAYS], 0, 8, ctx->stream));
+    TK_TRY(photon_pass_kind<0>(ctx, st));
+    if (s->quota[1] > 0) TK_TRY(photon_pass_kind<1>(ctx, st));
+    else { s->n_loc[1] = 0; s->last_shot[1] = 0; }
+    if (s->world == 1) {
+        TK_TRY(install_map(ctx, 0, s->loc_pos[0].as<float>(), s->loc_pow[0].as<float>(), s->loc_dir[0].as<uint16_t>(),
+                           s->n_loc[0], s->last_shot[0]));
+        TK_TRY(install_map(ctx, 1, s->loc_pos[1].as<float>(), s->loc_pow[1].as<float>(), s->loc_dir[1].as<uint16_t>(),
+                           s->n_loc[1], s->last_shot[1]));
+    }
+    if (st) {
+        int64_t rays = 0;
+        TK_TRY(read_u64_counter(ctx, C_RAYS, true, &rays));
+        st->ms_photon += tm.stop();
+        st->rays += rays;
+        st->global_paths = s->last_shot[0]; st->caustic_paths = s->last_shot[1];
+        st->global_stored = s->n_loc[0]; st->caustic_stored = s->n_loc[1];
+        st->shoot_global = s->shoot[0]; st->shoot_caustic = s->shoot[1];
+    }
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_export_local_photons(tkhip_ctx* ctx, int which, float* pos, float* power, uint16_t* dir, int64_t cap,
+                                    int64_t* n, int64_t* shot) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_export_local_photons");
+    TK_REQUIRE(which == 0 || which == 1, TKHIP_E_ARG, "tkhip_sppm_export_local_photons: which must be 0 or 1");
+    SppmState* s = ctx->sppm;
+    int64_t cnt = s->n_loc[which];
+    TK_REQUIRE(cnt <= cap, TKHIP_E_LIMIT, "tkhip_sppm_export_local_photons: %lld photons, buffer holds %lld", (long long)cnt,
+               (long long)cap);
+    if (cnt > 0) {
+        TK_REQUIRE(pos && power && dir, TKHIP_E_ARG, "tkhip_sppm_export_local_photons: null buffer");
+        TK_HIP(hipMemcpyAsync(pos, s->loc_pos[which].p, (size_t)cnt * 12, hipMemcpyDeviceToDevice, ctx->stream));
+        TK_HIP(hipMemcpyAsync(power, s->loc_pow[which].p, (size_t)cnt * 12, hipMemcpyDeviceToDevice, ctx->stream));
+        TK_HIP(hipMemcpyAsync(dir, s->loc_dir[which].p, (size_t)cnt * 2, hipMemcpyDeviceToDevice, ctx->stream));
+        TK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (n) *n = cnt;
+    if (shot) *shot = s->last_shot[which];
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, const float* power, const uint16_t* dir,
+                               int64_t n, int64_t shot_total) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_set_map_photons");
+    TK_REQUIRE(which == 0 || which == 1, TKHIP_E_ARG, "tkhip_sppm_set_map_photons: which must be 0 or 1");
+    TK_REQUIRE(n == 0 || (pos && power && dir), TKHIP_E_ARG, "tkhip_sppm_set_map_photons: null buffer");
+    TK_TRY(install_map(ctx, which, pos, power, dir, n, shot_total));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_build_maps");
+    SppmState* s = ctx->sppm;
+    Timer tm(ctx->stream, st != nullptr);
+    TK_TRY(map_build(s->map[0]));
+    if (s->stored_c > 0) TK_TRY(map_build(s->map[1]));   // src/tracer/TkSppmTracer.cpp:477-478
+    if (st) st->ms_build += tm.stop();
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_camera_pass");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->map[0]->built, TKHIP_E_STATE, "tkhip_sppm_camera_pass: build the photon maps first");
+    hipStream_t stream = ctx->stream;
+    int32_t* counters = s->counters.as<int32_t>();
+    int64_t ng = 0, nc = 0;
+    if (s->n_slots > 0) {
+        Timer tcam(stream, st != nullptr);
+        CameraArgs a;
+        a.sc = ctx->scene; a.cam = ctx->cam;
+        a.st = PathState{s->st_o.as<float4>(), s->st_d.as<float4>(), s->st_w.as<float4>()};
+        a.rows = s->rows.as<int32_t>();
+        a.planes = s->planes.as<float>();
+        a.n_pixels = s->n_pixels;
+        a.iter = iter; a.spp = s->num_recurse; a.xs = s->xs; a.ys = s->ys; a.depth = s->max_depth;
+        a.seed = s->seed;
+        a.caustic_stored = (int)s->stored_c;
+        a.gq = s->qbuf[0].as<float4>();
+        a.cq = s->qbuf[1].as<float4>();
+        a.qcap = s->n_slots;
+        TK_HIP(hipMemsetAsync(counters, 0, 4 * 4, stream));
+        TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 16, stream));
+        int32_t* qa = s->queue_a.as<int32_t>();
+        int32_t* qb = s->queue_b.as<int32_t>();
+        k_camera_gen<<<divup(s->n_slots, 256), 256, 0, stream>>>(a, s->n_slots, qa);
+        int32_t nslots32 = (int32_t)s->n_slots;
+        TK_HIP(hipMemcpyAsync(&counters[C_QA], &nslots32, 4, hipMemcpyHostToDevice, stream));
+        TK_LAUNCH_CHECK();
+        int64_t live_bound = s->n_slots;
+        int ca = C_QA, cb = C_QB;
+        for (int b = 0; b < s->max_depth; ++b) {
+            TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
+            k_camera_bounce<<<divup(live_bound, 256), 256, 0, stream>>>(a, b, qa, &counters[ca], qb, counters, cb);
+            TK_LAUNCH_CHECK();
+            std::swap(qa, qb);
+            std::swap(ca, cb);
+            if (b == 1 || b == 3 || b == 7 || b == 15 || b == 31) {
+                int32_t live = 0;
+                TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
+                TK_HIP(hipStreamSynchronize(stream));
+                if (live == 0) break;
+                live_bound = live;
+            }
+        }
+        int32_t hc[4];
+        TK_HIP(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, stream));
+        TK_HIP(hipStreamSynchronize(stream));
+        ng = hc[C_NGQ]; nc = hc[C_NCQ];
+        if (st) st->ms_camera += tcam.stop();
+        // gathers with the fused pixel update
+        Timer tg(stream, st != nullptr);
+        float group_ms = 0.f;
+        for (int which = 1; which >= 0; --which) {
+            int64_t nq = which == 0 ? ng : nc;
+            if (nq == 0) continue;
+            float4* q = s->qbuf[which].as<float4>();
+            QueryView qv{q, q + s->n_slots, q + 2 * s->n_slots, q + 3 * s->n_slots};
+            GatherOut out{};
+            out.planes = s->planes.as<float>();
+            out.n_pixels = s->n_pixels;
+            out.which = which;
+            out.photon_sum = reinterpret_cast<unsigned long long*>(&counters[C_PHOT]);
+            TK_TRY(map_gather_device(s->map[which], nq, qv, out, 0, st != nullptr));
+            group_ms += s->map[which]->last_group_ms;
+        }
+        if (st) {
+            st->ms_gather += tg.stop();
+            st->ms_gather_kernel += group_ms;
+        }
+    }
+    if (st) {
+        int64_t rays = 0, phot = 0;
+        TK_TRY(read_u64_counter(ctx, C_RAYS, true, &rays));
+        TK_TRY(read_u64_counter(ctx, C_PHOT, true, &phot));
+        st->rays += rays;
+        st->gathers_global += ng; st->gathers_caustic += nc; st->gather_photons += phot;
+    }
+    TK_HIP(hipStreamSynchronize(stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_iteration");
+    TK_REQUIRE(ctx->sppm->world == 1, TKHIP_E_STATE,
+               "tkhip_sppm_iteration: with world > 1 drive the passes and the photon exchange separately");
+    Timer tm(ctx->stream, st != nullptr);
+    TK_TRY(tkhip_sppm_photon_pass(ctx, iter, st));
+    TK_TRY(tkhip_sppm_build_maps(ctx, st));
+    TK_TRY(tkhip_sppm_camera_pass(ctx, iter, st));
+    if (st) {
+        st->ms_total += tm.stop();
+        st->shoot_global = ctx->sppm->shoot[0]; st->shoot_caustic = ctx->sppm->shoot[1];
+    }
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_read_pixels(tkhip_ctx* ctx, TkSPPMPixel* host_out) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_read_pixels");
+    TK_REQUIRE(host_out, TKHIP_E_ARG, "tkhip_sppm_read_pixels: null buffer");
+    SppmState* s = ctx->sppm;
+    TK_TRY(ctx->scratch_a.ensure((size_t)s->n_pixels * 52));
+    k_planes_to_aos<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels,
+                                                                     ctx->scratch_a.as<float>());
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(host_out, ctx->scratch_a.p, (size_t)s->n_pixels * 52, hipMemcpyDeviceToHost, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_export_planes(tkhip_ctx* ctx, float* device_dst) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_export_planes");
+    TK_REQUIRE(device_dst, TKHIP_E_ARG, "tkhip_sppm_export_planes: null buffer");
+    SppmState* s = ctx->sppm;
+    TK_HIP(hipMemcpyAsync(device_dst, s->planes.p, (size_t)s->n_pixels * 52, hipMemcpyDeviceToDevice, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_import_planes(tkhip_ctx* ctx, const float* device_src) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_import_planes");
+    TK_REQUIRE(device_src, TKHIP_E_ARG, "tkhip_sppm_import_planes: null buffer");
+    SppmState* s = ctx->sppm;
+    TK_HIP(hipMemcpyAsync(s->planes.p, device_src, (size_t)s->n_pixels * 52, hipMemcpyDeviceToDevice, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_resolve_rgb8(tkhip_ctx* ctx, int iterations, uint8_t* host_out) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_resolve_rgb8");
+    TK_REQUIRE(host_out && iterations >= 1, TKHIP_E_ARG, "tkhip_sppm_resolve_rgb8: bad argument");
+    SppmState* s = ctx->sppm;
+    TK_TRY(ctx->scratch_a.ensure((size_t)s->n_pixels * 3));
+    k_resolve<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, ctx->cam.w, ctx->cam.h,
+                                                               iterations, (float)(int32_t)s->shoot[0],
+                                                               (float)(int32_t)s->shoot[1], (int)s->stored_c,
+                                                               ctx->scratch_a.as<uint8_t>());
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(host_out, ctx->scratch_a.p, (size_t)s->n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_counters(tkhip_ctx* ctx, int64_t* shoot_global, int64_t* shoot_caustic, int32_t* num_recurse) {
+    TK_REQUIRE(ctx && ctx->sppm, TKHIP_E_STATE, "tkhip_sppm_counters: call tkhip_sppm_begin first");
+    if (shoot_global) *shoot_global = ctx->sppm->shoot[0];
+    if (shoot_caustic) *shoot_caustic = ctx->sppm->shoot[1];
+    if (num_recurse) *num_recurse = ctx->sppm->num_recurse;
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_read_photons(tkhip_ctx* ctx, int which, float* pos, float* power, uint8_t* theta, uint8_t* phi,
+                            int64_t* n) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_read_photons");
+    TK_REQUIRE(which == 0 || which == 1, TKHIP_E_ARG, "tkhip_sppm_read_photons: which must be 0 or 1");
+    SppmState* s = ctx->sppm;
+    tkhip_map* m = s->map[which];
+    int64_t cnt = m->n;
+    if (n) *n = cnt;
+    if (cnt == 0) return TKHIP_OK;
+    hipStream_t st = ctx->stream;
+    if (pos) TK_HIP(hipMemcpyAsync(pos, m->in_pos.p, (size_t)cnt * 12, hipMemcpyDeviceToHost, st));
+    if (power) TK_HIP(hipMemcpyAsync(power, m->in_pow.p, (size_t)cnt * 12, hipMemcpyDeviceToHost, st));
+    if (theta || phi) {
+        TK_TRY(ctx->scratch_b.ensure((size_t)cnt * 2));
+        uint8_t* d = ctx->scratch_b.as<uint8_t>();
+        k_unpack_dir<<<divup(cnt, 256), 256, 0, st>>>(m->in_dir.as<uint16_t>(), d, d + cnt, cnt);
+        TK_LAUNCH_CHECK();
+        if (theta) TK_HIP(hipMemcpyAsync(theta, d, (size_t)cnt, hipMemcpyDeviceToHost, st));
+        if (phi) TK_HIP(hipMemcpyAsync(phi, d + cnt, (size_t)cnt, hipMemcpyDeviceToHost, st));
+    }
+    TK_HIP(hipStreamSynchronize(st));
+    return TKHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// tk_api.hip — context lifecycle, scene / camera upload and the small
+// kernel-level entry points of the C ABI (include/tkhip.h).
+#include <algorithm>
+#include <cmath>
+
+#include "photon_map.h"
+#include "tk_bvh_device.h"
+
+namespace tkd {
+
+static thread_local char g_error[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+// PhotonMap ctor tables, src/tracer/Photonmap.cpp:26-33: computed in double,
+// stored as float.
+int upload_direction_tables(tkhip_ctx* ctx) {
+    if (ctx->b_dirtab.p) return TKHIP_OK;
+    TK_TRY(ctx->b_dirtab.ensure(1024 * 4));
+    float tab[1024];
+    const float pi = float(4.0 * std::atan(1.0));
+    for (int i = 0; i < 256; ++i) {
+        double radians = double(i) * pi / 255.0;
+        tab[i] = float(std::cos(radians));
+        tab[256 + i] = float(std::sin(radians));
+        tab[512 + i] = float(std::cos(2.0 * radians));
+        tab[768 + i] = float(std::sin(2.0 * radians));
+    }
+    TK_HIP(hipMemcpy(ctx->b_dirtab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
+    return TKHIP_OK;
+}
+
+__global__ void __launch_bounds__(256) k_trace_rays(DScene sc, int64_t n, const float* org, const float* dir,
+                                                    const float* tmax, int32_t* prim, float* t, float* p, float* nrm,
+                                                    float* perr) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
+    double tm = tmax ? (double)tmax[i] : 1.7976931348623157e308;
+    Hit h = trace_ray<false>(sc, o, d, tm, stk);
+    prim[i] = h.prim;
+    SurfacePoint sp{};
+    if (h.prim >= 0) sp = surface_at(sc, h, o, d);
+    if (t) t[i] = h.prim >= 0 ? (float)h.t : 0.f;
+    if (p) { p[3 * i] = sp.p.x; p[3 * i + 1] = sp.p.y; p[3 * i + 2] = sp.p.z; }
+    if (nrm) { nrm[3 * i] = sp.n.x; nrm[3 * i + 1] = sp.n.y; nrm[3 * i + 2] = sp.n.z; }
+    if (perr) { perr[3 * i] = sp.perr.x; perr[3 * i + 1] = sp.perr.y; perr[3 * i + 2] = sp.perr.z; }
+}
+
+__global__ void k_radical_inverse(int64_t n, const int32_t* dim, const uint64_t* index, float* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = radical_inverse(dim[i], index[i]);
+}
+
+__global__ void k_camera_rays(DCamera cam, int64_t n, const float* raster, float* org, float* dir) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 o, d;
+    camera_ray(cam, raster[2 * i], raster[2 * i + 1], &o, &d);
+    org[3 * i] = o.x; org[3 * i + 1] = o.y; org[3 * i + 2] = o.z;
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+}
+
+template <class T>
+static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
+    TK_TRY(b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) TK_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return TKHIP_OK;
+}
+
+}  // namespace tkd
+
+using namespace tkd;
+
+extern "C" {
+
+const char* tkhip_last_error(void) { return tkd::g_error; }
+
+const char* tkhip_version(void) { return "tkhip 0.1 gfx950"; }
+
+int tkhip_create(int device, tkhip_ctx** out) {
+    TK_REQUIRE(out, TKHIP_E_ARG, "tkhip_create: null output pointer");
+    int count = 0;
+    TK_HIP(hipGetDeviceCount(&count));
+    TK_REQUIRE(device >= 0 && device < count, TKHIP_E_ARG, "tkhip_create: device %d of %d", device, count);
+    TK_HIP(hipSetDevice(device));
+    tkhip_ctx* ctx = new tkhip_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("tkhip_create: hipStreamCreate: %s", hipGetErrorString(e));
+        delete ctx;
+        return TKHIP_E_HIP;
+    }
+    int rc = upload_direction_tables(ctx);
+    if (rc) { tkhip_destroy(ctx); return rc; }
+    *out = ctx;
+    return TKHIP_OK;
+}
+
+void tkhip_destroy(tkhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    destroy_sppm(ctx);
+    DevBuf* bufs[] = {&ctx->b_nodes, &ctx->b_tri_isect, &ctx->b_tri_shade, &ctx->b_spheres, &ctx->b_prim_mat,
+                      &ctx->b_mats, &ctx->b_lights, &ctx->b_cdf, &ctx->b_dirtab, &ctx->scratch_a, &ctx->scratch_b,
+                      &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->scratch_f, &ctx->prim_temp};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, const TkTriangle* tris, int n_tris,
+                    const TkSphere* spheres, int n_spheres, const TkMaterial* materials, int n_materials,
+                    const TkLight* lights, int n_lights) {
+    TK_REQUIRE(ctx, TKHIP_E_ARG, "tkhip_set_scene: null context");
+    TK_REQUIRE(n_objects >= 0 && n_tris >= 0 && n_spheres >= 0 && n_materials >= 1 && n_lights >= 0, TKHIP_E_ARG,
+               "tkhip_set_scene: negative count or no material");
+    TK_REQUIRE((n_objects == 0 || objects) && (n_tris == 0 || tris) && (n_spheres == 0 || spheres) && materials &&
+                   (n_lights == 0 || lights),
+               TKHIP_E_ARG, "tkhip_set_scene: null array");
+    TK_REQUIRE((int64_t)n_tris + n_spheres < (int64_t)1 << 28, TKHIP_E_LIMIT, "tkhip_set_scene: too many primitives");
+    TK_REQUIRE(n_materials < 65536 && n_lights < 32767, TKHIP_E_LIMIT, "tkhip_set_scene: too many materials or lights");
+    TK_REQUIRE(ctx->sppm == nullptr, TKHIP_E_STATE, "tkhip_set_scene: a render is in progress on this context");
+    TK_HIP(hipSetDevice(ctx->device));
+    // per-primitive material / light from the owning object
+    std::vector<int32_t> prim_mat((size_t)n_tris + n_spheres, 0);
+    std::vector<char> covered((size_t)n_tris + n_spheres, 0);
+    for (int o = 0; o < n_objects; ++o) {
+        const TkObject& ob = objects[o];
+        TK_REQUIRE(ob.material >= 0 && ob.material < n_materials, TKHIP_E_ARG, "object %d: material %d out of range", o, ob.material);
+        TK_REQUIRE(ob.light >= -1 && ob.light < n_lights, TKHIP_E_ARG, "object %d: light %d out of range", o, ob.light);
+        int lim = ob.kind == 0 ? n_tris : n_spheres;
+        TK_REQUIRE((ob.kind == 0 || ob.kind == 1) && ob.first >= 0 && ob.count >= 0 && ob.first + ob.count <= lim,
+                   TKHIP_E_ARG, "object %d: primitive range out of bounds", o);
+        for (int i = 0; i < ob.count; ++i) {
+            size_t id = ob.kind == 0 ? (size_t)(ob.first + i) : (size_t)(n_tris + ob.first + i);
+            prim_mat[id] = ob.material | ((ob.light + 1) << 16);
+            covered[id] = 1;
+        }
+    }
+    for (size_t i = 0; i < covered.size(); ++i)
+        TK_REQUIRE(covered[i], TKHIP_E_ARG, "primitive %zu belongs to no object", i);
+    for (int m = 0; m < n_materials; ++m)
+        TK_REQUIRE(materials[m].type == TK_DIFFUSE || materials[m].type == TK_MIRROR || materials[m].type == TK_GLASS,
+                   TKHIP_E_ARG, "material %d: unsupported type %d", m, materials[m].type);
+
+    HostBvh bvh;
+    build_bvh(tris, n_tris, spheres, n_spheres, 4, kStackDepth, &bvh);
+    TK_REQUIRE(bvh.max_depth < kStackDepth - 1, TKHIP_E_LIMIT, "scene BVH depth %d exceeds the traversal stack", bvh.max_depth);
+
+    const size_t nprim = (size_t)n_tris + n_spheres;
+    std::vector<TriIsect> isect(nprim);
+    for (size_t s = 0; s < nprim; ++s) {
+        int id = bvh.order[s];
+        TriIsect& t = isect[s];
+        memset(&t, 0, sizeof(t));
+        t.prim = id;
+        if (id < n_tris) {
+            for (int a = 0; a < 3; ++a) {
+                t.v0[a] = tris[id].v0[a];
+                t.e1[a] = tris[id].v1[a] - tris[id].v0[a];   // src/Triangle.hpp:21-22
+                t.e2[a] = tris[id].v2[a] - tris[id].v0[a];
+            }
+        }
+    }
+    std::vector<TriShade> shade((size_t)std::max(n_tris, 1));
+    std::vector<float> area((size_t)std::max(n_tris, 1), 0.f);
+    for (int i = 0; i < n_tris; ++i) {
+        TriShade& t = shade[(size_t)i];
+        float e1[3], e2[3];
+        for (int a = 0; a < 3; ++a) {
+            t.v0[a] = tris[i].v0[a]; t.v1[a] = tris[i].v1[a]; t.v2[a] = tris[i].v2[a];
+            e1[a] = tris[i].v1[a] - tris[i].v0[a];
+            e2[a] = tris[i].v2[a] - tris[i].v0[a];
+        }
+        // normal = normalize(e1 x e2), area = |e1 x e2| / 2 (src/Triangle.hpp:23-24, src/Vector.hpp:80-103)
+        float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        float mag2 = cx * cx + cy * cy + cz * cz;
+        if (mag2 > 0) {
+            float inv = 1 / sqrtf(mag2);
+            t.nx = cx * inv; t.ny = cy * inv; t.nz = cz * inv;
+        } else { t.nx = cx; t.ny = cy; t.nz = cz; }
+        area[(size_t)i] = sqrtf(cx * cx + cy * cy + cz * cz) * 0.5f;
+    }
+    std::vector<float4> sph((size_t)std::max(n_spheres, 1));
+    for (int j = 0; j < n_spheres; ++j)
+        sph[(size_t)j] = make_float4(spheres[j].center[0], spheres[j].center[1], spheres[j].center[2], spheres[j].radius);
+    // lights: Distribution1D over the triangle areas of the emitting mesh
+    // (src/Triangle.cpp:170-178, src/core/sampling.h:57-66)
+    std::vector<DLight> dl((size_t)std::max(n_lights, 1));
+    std::vector<float> cdf;
+    for (int l = 0; l < n_lights; ++l) {
+        TK_REQUIRE(lights[l].object >= 0 && lights[l].object < n_objects, TKHIP_E_ARG, "light %d: object out of range", l);
+        const TkObject& ob = objects[lights[l].object];
+        TK_REQUIRE(ob.kind == 0 && ob.count > 0, TKHIP_E_ARG, "light %d: the emitting object must be a non-empty mesh", l);
+        DLight& d = dl[(size_t)l];
+        memcpy(d.Le, lights[l].Le, sizeof(d.Le));
+        d.two_sided = lights[l].two_sided;
+        d.tri_first = ob.first; d.tri_count = ob.count;
+        d.cdf_first = (int32_t)cdf.size();
+        size_t base = cdf.size();
+        cdf.resize(base + (size_t)ob.count + 1);
+        cdf[base] = 0;
+        float total = 0;
+        for (int i = 1; i < ob.count + 1; ++i) {
+            float f = area[(size_t)(ob.first + i - 1)];
+            total += f;
+            cdf[base + (size_t)i] = cdf[base + (size_t)i - 1] + f / ob.count;
+        }
+        float c = cdf[base + (size_t)ob.count];
+        for (int i = 1; i < ob.count + 1; ++i) cdf[base + (size_t)i] /= c;
+        d.area = total;
+    }
+    std::vector<TkMaterial> mats(materials, materials + n_materials);
+    ctx->h_mats = mats;
+    hipStream_t s = ctx->stream;
+    TK_TRY(upload(ctx->b_nodes, bvh.nodes, s));
+    TK_TRY(upload(ctx->b_tri_isect, isect, s));
+    TK_TRY(upload(ctx->b_tri_shade, shade, s));
+    TK_TRY(upload(ctx->b_spheres, sph, s));
+    TK_TRY(upload(ctx->b_prim_mat, prim_mat, s));
+    TK_TRY(upload(ctx->b_mats, mats, s));
+    TK_TRY(upload(ctx->b_lights, dl, s));
+    TK_TRY(upload(ctx->b_cdf, cdf, s));
+    TK_HIP(hipStreamSynchronize(s));
+    DScene& sc = ctx->scene;
+    sc.nodes = ctx->b_nodes.as<BvhNode>();
+    sc.tri_isect = ctx->b_tri_isect.as<TriIsect>();
+    sc.tri_shade = ctx->b_tri_shade.as<TriShade>();
+    sc.spheres = ctx->b_spheres.as<float4>();
+    sc.prim_mat = ctx->b_prim_mat.as<int32_t>();
+    sc.mats = ctx->b_mats.as<TkMaterial>();
+    sc.lights = ctx->b_lights.as<DLight>();
+    sc.light_cdf = ctx->b_cdf.as<float>();
+    sc.n_tris = n_tris; sc.n_spheres = n_spheres; sc.n_lights = n_lights;
+    sc.n_nodes = (int32_t)bvh.nodes.size();
+    sc.root_leaf = bvh.root_leaf;
+    for (int a = 0; a < 3; ++a) { sc.bmin[a] = bvh.bmin[a]; sc.bmax[a] = bvh.bmax[a]; }
+    ctx->has_scene = true;
+    return TKHIP_OK;
+}
+
+int tkhip_set_camera(tkhip_ctx* ctx, const float c2w[16], const float raster2cam[16], int width, int height) {
+    TK_REQUIRE(ctx && c2w && raster2cam, TKHIP_E_ARG, "tkhip_set_camera: null argument");
+    TK_REQUIRE(width >= 1 && height >= 1 && (int64_t)width * height < (int64_t)1 << 30, TKHIP_E_LIMIT,
+               "tkhip_set_camera: image size %dx%d out of range", width, height);
+    TK_REQUIRE(ctx->sppm == nullptr, TKHIP_E_STATE, "tkhip_set_camera: a render is in progress on this context");
+    memcpy(ctx->cam.c2w, c2w, sizeof(float) * 16);
+    memcpy(ctx->cam.r2c, raster2cam, sizeof(float) * 16);
+    ctx->cam.w = width;
+    ctx->cam.h = height;
+    ctx->has_camera = true;
+    return TKHIP_OK;
+}
+
+int tkhip_trace_rays(tkhip_ctx* ctx, int64_t n, const float* org, const float* dir, const float* tmax, int32_t* prim,
+                     float* t, float* p, float* nrm, float* perr) {
+    TK_REQUIRE(ctx && (n == 0 || (org && dir && prim)), TKHIP_E_ARG, "tkhip_trace_rays: null argument");
+    TK_REQUIRE(ctx->has_scene, TKHIP_E_STATE, "tkhip_trace_rays: no scene set");
+    TK_REQUIRE(n >= 0 && n < (int64_t)1 << 31, TKHIP_E_LIMIT, "tkhip_trace_rays: ray count out of range");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    const size_t q = (size_t)n;
+    DevBuf in, out;
+    int rc = in.ensure(q * 28);
+    if (!rc) rc = out.ensure(q * 44);
+    if (rc) { in.release(); out.release(); return rc; }
+    hipStream_t s = ctx->stream;
+    float* dorg = in.as<float>();
+    float* ddir = dorg + 3 * q;
+    float* dtm = ddir + 3 * q;
+    int32_t* dprim = out.as<int32_t>();
+    float* dt = out.as<float>() + q;
+    float* dp = dt + q;
+    float* dn = dp + 3 * q;
+    float* de = dn + 3 * q;
+    hipError_t e = hipMemcpyAsync(dorg, org, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ddir, dir, q * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && tmax) e = hipMemcpyAsync(dtm, tmax, q * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        k_trace_rays<<<divup(n, kTraceBlock), kTraceBlock, 0, s>>>(ctx->scene, n, dorg, ddir, tmax ? dtm : nullptr, dprim, dt,
+                                                                 dp, dn, de);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(prim, dprim, q * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && t) e = hipMemcpy(t, dt, q * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && p) e = hipMemcpy(p, dp, q * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nrm) e = hipMemcpy(nrm, dn, q * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && perr) e = hipMemcpy(perr, de, q * 12, hipMemcpyDeviceToHost);
+    in.release();
+    out.release();
+    if (e != hipSuccess) { set_error("tkhip_trace_rays: %s", hipGetErrorString(e)); return TKHIP_E_HIP; }
+    return TKHIP_OK;
+}
+
+int tkhip_radical_inverse(tkhip_ctx* ctx, int64_t n, const int32_t* dim, const uint64_t* index, float* out) {
+    TK_REQUIRE(ctx && (n == 0 || (dim && index && out)), TKHIP_E_ARG, "tkhip_radical_inverse: null argument");
+    if (n == 0) return TKHIP_OK;
+    for (int64_t i = 0; i < n; ++i)
+        TK_REQUIRE(dim[i] >= 0 && dim[i] < 16, TKHIP_E_LIMIT, "tkhip_radical_inverse: dimension %d outside 0..15", dim[i]);
+    TK_HIP(hipSetDevice(ctx->device));
+    const size_t q = (size_t)n;
+    DevBuf b;
+    TK_TRY(b.ensure(q * 16));
+    uint64_t* di = b.as<uint64_t>();
+    int32_t* dd = (int32_t*)(di + q);
+    float* dout = (float*)(dd + q);
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemcpyAsync(di, index, q * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd, dim, q * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        k_radical_inverse<<<divup(n, 256), 256, 0, s>>>(n, dd, di, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, q * 4, hipMemcpyDeviceToHost);
+    b.release();
+    if (e != hipSuccess) { set_error("tkhip_radical_inverse: %s", hipGetErrorString(e)); return TKHIP_E_HIP; }
+    return TKHIP_OK;
+}
+
+int tkhip_camera_rays(tkhip_ctx* ctx, int64_t n, const float* raster, float* org, float* dir) {
+    TK_REQUIRE(ctx && (n == 0 || (raster && org && dir)), TKHIP_E_ARG, "tkhip_camera_rays: null argument");
+    TK_REQUIRE(ctx->has_camera, TKHIP_E_STATE, "tkhip_camera_rays: no camera set");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    const size_t q = (size_t)n;
+    DevBuf b;
+    TK_TRY(b.ensure(q * 32));
+    float* dr = b.as<float>();
+    float* dorg = dr + 2 * q;
+    float* ddir = dorg + 3 * q;
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemcpyAsync(dr, raster, q * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        k_camera_rays<<<divup(n, 256), 256, 0, s>>>(ctx->cam, n, dr, dorg, ddir);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(org, dorg, q * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(dir, ddir, q * 12, hipMemcpyDeviceToHost);
+    b.release();
+    if (e != hipSuccess) { set_error("tkhip_camera_rays: %s", hipGetErrorString(e)); return TKHIP_E_HIP; }
+    return TKHIP_OK;
+}
+
+}  // extern "C"

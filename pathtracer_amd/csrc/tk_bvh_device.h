@@ -1,0 +1,270 @@
+// tk_bvh_device.h — ray queries against the flattened scene BVH: closest hit
+// and occlusion, with the per-lane traversal stack in LDS.
+//
+// The CPU renderer walks a two-level BVH (objects, then one BVH per mesh), far
+// child first and without culling boxes against the current hit
+// (src/BVH.cpp:245-288, src/Bounds3.hpp:96-125).  Here one BVH covers every
+// triangle and sphere, the near child is visited first and boxes beyond the
+// current hit are skipped; the closest hit is the same because every
+// primitive test and the strict `t < t_max` update rule are kept
+// (src/Triangle.cpp:15-52, src/Sphere.cpp:14-55).
+#pragma once
+#include "tk_device.h"
+
+namespace tkd {
+
+constexpr int kStackDepth = 40;      // per-lane entries; the builder bounds the tree depth
+constexpr int kTraceBlock = 256;     // threads per block of every kernel that traces
+
+// LDS stack: entry e of lane t lives at stack[e * kTraceBlock + t] so that the
+// 64 lanes of a wave touch 64 consecutive banks.
+struct LdsStack {
+    int* base;
+    TKD void push(int sp, int v) { base[sp * kTraceBlock] = v; }
+    TKD int pop(int sp) { return base[sp * kTraceBlock]; }
+};
+
+struct Hit {
+    int prim;        // original primitive id, -1 = miss
+    double t;        // r.t_max after the query
+    double u, v;     // barycentrics of a triangle hit
+};
+
+struct SurfacePoint {
+    F3 p, perr, n, wo;
+    int mat;         // material index
+    int light;       // light index or -1
+};
+
+// Interval arithmetic of src/EFloat.h:8-144 for the sphere quadratic.
+struct EF {
+    float v, lo, hi;
+};
+TKD EF ef_make(float v) { EF r; r.v = v; r.lo = v; r.hi = v; return r; }
+TKD EF ef_make_err(float v, float err) {
+    EF r; r.v = v;
+    if (err == 0.0f) { r.lo = v; r.hi = v; }
+    else { r.lo = next_down(v - err); r.hi = next_up(v + err); }
+    return r;
+}
+TKD EF ef_add(EF a, EF b) { EF r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
+TKD EF ef_sub(EF a, EF b) { EF r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
+TKD float std_min(float a, float b) { return b < a ? b : a; }
+TKD float std_max(float a, float b) { return a < b ? b : a; }
+TKD EF ef_mul(EF a, EF b) {
+    EF r; r.v = a.v * b.v;
+    float p0 = a.lo * b.lo, p1 = a.hi * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.hi;
+    r.lo = next_down(std_min(std_min(p0, p1), std_min(p2, p3)));
+    r.hi = next_up(std_max(std_max(p0, p1), std_max(p2, p3)));
+    return r;
+}
+TKD EF ef_div(EF a, EF b) {
+    EF r; r.v = a.v / b.v;
+    if (b.lo < 0 && b.hi > 0) { r.lo = -INFINITY; r.hi = INFINITY; }
+    else {
+        float d0 = a.lo / b.lo, d1 = a.hi / b.lo, d2 = a.lo / b.hi, d3 = a.hi / b.hi;
+        r.lo = next_down(std_min(std_min(d0, d1), std_min(d2, d3)));
+        r.hi = next_up(std_max(std_max(d0, d1), std_max(d2, d3)));
+    }
+    return r;
+}
+TKD bool ef_quadratic(EF a, EF b, EF c, EF* t0, EF* t1) {      // src/EFloat.h:125-143
+    float discrim = b.v * b.v - 4.0f * a.v * c.v;
+    if (discrim < 0) return false;
+    float root = sqrtf(discrim);
+    EF froot = ef_make_err(root, kEps * root);
+    EF q;
+    if (b.v < 0) q = ef_mul(ef_sub(b, froot), ef_make(-0.5f));
+    else q = ef_mul(ef_add(b, froot), ef_make(-0.5f));
+    *t0 = ef_div(q, a);
+    *t1 = ef_div(c, q);
+    if (t0->v > t1->v) { EF t = *t0; *t0 = *t1; *t1 = t; }
+    return true;
+}
+
+// Sphere::intersect up to the choice of the root (src/Sphere.cpp:14-37).
+TKD bool sphere_hit_t(float4 sph, F3 o, F3 d, double tmax, float* thit) {
+    EF ox = ef_sub(ef_make(o.x), ef_make(sph.x));
+    EF oy = ef_sub(ef_make(o.y), ef_make(sph.y));
+    EF oz = ef_sub(ef_make(o.z), ef_make(sph.z));
+    EF dx = ef_make(d.x), dy = ef_make(d.y), dz = ef_make(d.z);
+    EF a = ef_add(ef_add(ef_mul(dx, dx), ef_mul(dy, dy)), ef_mul(dz, dz));
+    EF b = ef_mul(ef_add(ef_add(ef_mul(dx, ox), ef_mul(dy, oy)), ef_mul(dz, oz)), ef_make(2.0f));
+    EF rr = ef_make(sph.w);
+    EF c = ef_sub(ef_add(ef_add(ef_mul(ox, ox), ef_mul(oy, oy)), ef_mul(oz, oz)), ef_mul(rr, rr));
+    EF t0, t1;
+    if (!ef_quadratic(a, b, c, &t0, &t1)) return false;
+    if ((double)t0.hi > tmax || t1.lo <= 0) return false;
+    EF hit = t0;
+    if (hit.lo <= 0) {
+        hit = t1;
+        if ((double)hit.hi > tmax) return false;
+    }
+    *thit = hit.v;
+    return true;
+}
+
+// Triangle::intersect (src/Triangle.cpp:15-37): fp32 products, fp64 scalars.
+TKD bool tri_hit(const TriIsect& T, F3 o, F3 d, double tmax, double* tout, double* uout, double* vout) {
+    F3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+    F3 pvec = cross3(d, e2);
+    double det = (double)dot3(e1, pvec);
+    if (fabs(det) < (double)kEps) return false;
+    double det_inv = 1. / det;
+    F3 tvec = sub3(o, ld3(T.v0));
+    double u = (double)dot3(tvec, pvec) * det_inv;
+    if (u < 0 || u > 1) return false;
+    F3 qvec = cross3(tvec, e1);
+    double v = (double)dot3(d, qvec) * det_inv;
+    if (v < 0 || u + v > 1) return false;
+    double t = (double)dot3(e2, qvec) * det_inv;
+    if (t > 0 && t < tmax) { *tout = t; *uout = u; *vout = v; return true; }
+    return false;
+}
+
+// Slab test with the tMax padding of src/Bounds3.hpp:108-118; returns the
+// entry distance.  fminf/fmaxf drop NaNs from 0*inf, which only ever widens
+// the interval.
+TKD bool box_hit(const float* bmin, const float* bmax, F3 o, F3 dinv, float tmax, float* tnear) {
+    const float pad = 1 + 2 * gamma_n(3);
+    float tx0 = (bmin[0] - o.x) * dinv.x, tx1 = (bmax[0] - o.x) * dinv.x;
+    float ty0 = (bmin[1] - o.y) * dinv.y, ty1 = (bmax[1] - o.y) * dinv.y;
+    float tz0 = (bmin[2] - o.z) * dinv.z, tz1 = (bmax[2] - o.z) * dinv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * pad;
+    *tnear = tn;
+    return tn <= tf && tf > 0 && tn < tmax;
+}
+
+template <bool ANY_HIT>
+TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int64_t* nprims) {
+    int first = enc >> 3, count = (enc & 7) + 1;
+    for (int i = 0; i < count; ++i) {
+        const TriIsect T = sc.tri_isect[first + i];
+        if (nprims) ++*nprims;
+        if (T.prim < sc.n_tris) {
+            double t, u, v;
+            if (tri_hit(T, o, d, h->t, &t, &u, &v)) { h->t = t; h->u = u; h->v = v; h->prim = T.prim; }
+        } else {
+            float th;
+            if (sphere_hit_t(sc.spheres[T.prim - sc.n_tris], o, d, h->t, &th)) { h->t = (double)th; h->prim = T.prim; }
+        }
+    }
+}
+
+// Closest hit (ANY_HIT = false) or occlusion (ANY_HIT = true: stops at the
+// first hit below tmax, enough for the boolean Scene::intersectP answers,
+// src/core/Scene.cpp:27-31).
+template <bool ANY_HIT>
+TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, LdsStack st) {
+    Hit h;
+    h.prim = -1; h.t = tmax; h.u = 0; h.v = 0;
+    if (sc.n_nodes == 0) {
+        if (sc.root_leaf != 0x7fffffff) leaf_test<ANY_HIT>(sc, sc.root_leaf, o, d, &h, nullptr);
+        return h;
+    }
+    // Ray ctor: direction_inv = float(1.0 / double(dir)) (src/Ray.hpp:21)
+    F3 dinv = mk3((float)(1. / (double)d.x), (float)(1. / (double)d.y), (float)(1. / (double)d.z));
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        const BvhNode nd = sc.nodes[node];
+        float tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
+        float tl, tr;
+        bool hl = box_hit(nd.lmin, nd.lmax, o, dinv, tcull, &tl);
+        bool hr = box_hit(nd.rmin, nd.rmax, o, dinv, tcull, &tr);
+        int near = nd.left, far = nd.right;
+        if (hl && hr && tr < tl) { near = nd.right; far = nd.left; }
+        else if (!hl) { near = nd.right; far = nd.left; }
+        int next = -1;
+        bool have_next = false;
+        if (hl || hr) {
+            if (near < 0) leaf_test<ANY_HIT>(sc, ~near, o, d, &h, nullptr);
+            else { next = near; have_next = true; }
+            if (hl && hr) {
+                if (far < 0) leaf_test<ANY_HIT>(sc, ~far, o, d, &h, nullptr);
+                else if (have_next) { st.push(sp, far); ++sp; }
+                else { next = far; have_next = true; }
+            }
+        }
+        if (ANY_HIT && h.prim >= 0) return h;
+        if (have_next) { node = next; continue; }
+        if (sp == 0) break;
+        --sp;
+        node = st.pop(sp);
+    }
+    return h;
+}
+
+// Fills the surface record of a hit: Triangle::intersect :39-48 or
+// Sphere::intersect :39-53, and the object's material / light.
+TKD SurfacePoint surface_at(const DScene& sc, const Hit& h, F3 o, F3 d) {
+    SurfacePoint s;
+    if (h.prim < sc.n_tris) {
+        const TriShade T = sc.tri_shade[h.prim];
+        double u = h.u, v = h.v, w = 1 - u - v;
+        float xs = (float)(fabs(w * T.v0[0]) + fabs(u * T.v1[0]) + fabs(v * T.v2[0]));
+        float ys = (float)(fabs(w * T.v0[1]) + fabs(u * T.v1[1]) + fabs(v * T.v2[1]));
+        float zs = (float)(fabs(w * T.v0[2]) + fabs(u * T.v1[2]) + fabs(v * T.v2[2]));
+        s.perr = scale3(mk3(xs, ys, zs), gamma_n(7));
+        s.p = add3(add3(scale3(ld3(T.v0), (float)w), scale3(ld3(T.v1), (float)u)), scale3(ld3(T.v2), (float)v));
+        s.n = mk3(T.nx, T.ny, T.nz);
+    } else {
+        float4 sph = sc.spheres[h.prim - sc.n_tris];
+        F3 center = mk3(sph.x, sph.y, sph.z);
+        F3 phit = add3(o, scale3(d, (float)h.t));
+        F3 dir = sub3(phit, center);
+        dir = divs3(scale3(dir, sph.w), norm3(dir));
+        F3 perr = scale3(abs3(dir), gamma_n(5));
+        phit = add3(dir, center);
+        perr = add3(scale3(perr, 1 + gamma_n(1)), scale3(add3(abs3(dir), abs3(center)), gamma_n(1)));
+        s.p = phit;
+        s.perr = perr;
+        s.n = normalize3(sub3(phit, center));
+    }
+    s.wo = normalize3(neg3(d));
+    int pm = sc.prim_mat[h.prim];
+    s.mat = pm & 0xffff;
+    s.light = (pm >> 16) - 1;
+    return s;
+}
+
+// ------------------------------------------------------------------ lights
+TKD int sample_discrete(const float* cdf, int n, float u, float* pdf) {   // src/TkMath.h:298-310, src/core/sampling.h:67-72
+    int sz = n + 1;
+    int size = sz - 2, first = 1;
+    while (size > 0) {
+        int half = size >> 1, middle = first + half;
+        bool pr = cdf[middle] <= u;
+        first = pr ? middle + 1 : first;
+        size = pr ? size - (half + 1) : half;
+    }
+    int off = first - 1;
+    off = off < 0 ? 0 : (off > sz - 2 ? sz - 2 : off);
+    *pdf = cdf[off + 1] - cdf[off];
+    return off;
+}
+struct LightPoint {
+    F3 p, n, perr;
+};
+// Triangle::Sample (src/Triangle.cpp:56-66) on triangle `tri` of the scene.
+TKD LightPoint tri_sample(const DScene& sc, int tri, float ux, float uy, float* pdf) {
+    const TriShade T = sc.tri_shade[tri];
+    F3 v0 = ld3(T.v0), v1 = ld3(T.v1), v2 = ld3(T.v2);
+    float su0 = sqrtf(ux);
+    float bx = 1 - su0, by = uy * su0;
+    LightPoint r;
+    r.p = add3(add3(scale3(v0, bx), scale3(v1, by)), scale3(v2, 1 - bx - by));
+    r.n = mk3(T.nx, T.ny, T.nz);
+    F3 s = add3(add3(abs3(scale3(v0, bx)), abs3(scale3(v1, by))), abs3(scale3(v2, 1 - bx - by)));
+    r.perr = scale3(s, gamma_n(6));
+    // Triangle ctor: area = |e1 x e2| * 0.5 (src/Triangle.hpp:21-24)
+    float area = norm3(cross3(sub3(v1, v0), sub3(v2, v0))) * 0.5f;
+    *pdf = 1 / area;
+    return r;
+}
+TKD F3 light_L(const DLight& l, F3 n, F3 w) {                  // src/Light.cpp:90-93
+    return (l.two_sided || dot3(n, w) > 0) ? ld3(l.Le) : mk3(0, 0, 0);
+}
+
+}  // namespace tkd

@@ -1,0 +1,174 @@
+// tk_common.h — host-side plumbing shared by the translation units of
+// libtkhip.so: error reporting, device buffers, the context object.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tkhip.h"
+
+namespace tkd {
+
+void set_error(const char* fmt, ...);
+
+#define TK_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            tkd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+            return TKHIP_E_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define TK_TRY(call)                 \
+    do {                             \
+        int _rc = (call);            \
+        if (_rc != TKHIP_OK) return _rc; \
+    } while (0)
+
+#define TK_REQUIRE(cond, code, ...)      \
+    do {                                 \
+        if (!(cond)) {                   \
+            tkd::set_error(__VA_ARGS__); \
+            return (code);               \
+        }                                \
+    } while (0)
+
+// Checks the launch itself (bad grid, missing code object); execution faults
+// surface at the next synchronisation.
+#define TK_LAUNCH_CHECK() TK_HIP(hipGetLastError())
+
+// A device allocation that grows on demand and is freed with its owner.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return TKHIP_OK;
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return TKHIP_E_NOMEM;
+        }
+        bytes = want;
+        return TKHIP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+inline int divup(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+
+// ------------------------------------------------------------ device scene
+// 64-byte BVH node: both child boxes live in the parent so one fetch decides
+// both descents.  child < 0 encodes a leaf: ~child = first_slot * 8 + (count-1).
+struct BvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// Per-slot triangle record for the intersection test (leaf order).
+struct TriIsect {
+    float v0[3], e1[3], e2[3];
+    int32_t prim;       // original primitive id (>= n_tris: sphere n_tris + j)
+    int32_t pad[2];
+};
+static_assert(sizeof(TriIsect) == 48, "TriIsect must be 48 bytes");
+
+// Per-primitive record read once for the winning hit (original order).
+struct TriShade {
+    float v0[3], nx;
+    float v1[3], ny;
+    float v2[3], nz;
+};
+static_assert(sizeof(TriShade) == 48, "TriShade must be 48 bytes");
+
+struct DLight {
+    float Le[3];
+    int32_t two_sided;
+    int32_t tri_first, tri_count;   // triangle range of the emitting mesh
+    int32_t cdf_first;              // offset into the light cdf array (tri_count+1 entries)
+    float area;
+};
+
+struct DScene {
+    const BvhNode* nodes;
+    const TriIsect* tri_isect;
+    const TriShade* tri_shade;
+    const float4* spheres;          // center.xyz, radius
+    const int32_t* prim_mat;        // material | (light+1) << 16, per original primitive id
+    const TkMaterial* mats;
+    const DLight* lights;
+    const float* light_cdf;
+    int32_t n_tris, n_spheres, n_lights, n_nodes;
+    int32_t root_leaf;              // >= 0: the whole scene is one leaf (encoded as child)
+    float bmin[3], bmax[3];
+};
+
+struct DCamera {
+    float c2w[16];
+    float r2c[16];
+    int32_t w, h;
+};
+
+struct HostBvh {
+    std::vector<BvhNode> nodes;
+    std::vector<int32_t> order;     // slot -> original primitive id
+    int32_t root_leaf = 0;
+    int max_depth = 0;
+    float bmin[3], bmax[3];
+};
+
+// Builds the flat two-children-per-node BVH over triangles followed by spheres.
+void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int n_spheres,
+               int max_leaf, int max_stack_depth, HostBvh* out);
+
+struct SppmState;
+
+}  // namespace tkd
+
+struct tkhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool has_scene = false, has_camera = false;
+    tkd::DScene scene{};
+    tkd::DCamera cam{};
+    tkd::DevBuf b_nodes, b_tri_isect, b_tri_shade, b_spheres, b_prim_mat, b_mats, b_lights, b_cdf;
+    tkd::DevBuf b_dirtab;           // 4 x 256 floats: cosTheta, sinTheta, cosPhi, sinPhi
+    tkd::DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e, scratch_f;
+    tkd::DevBuf prim_temp;          // rocPRIM temporary storage
+    tkd::SppmState* sppm = nullptr;
+    std::vector<TkMaterial> h_mats;
+};
+
+namespace tkd {
+
+// rocPRIM wrappers (tk_prims.hip).  All asynchronous on ctx->stream.
+int sort_pairs_u64(tkhip_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout,
+                   size_t n, int end_bit);
+int sort_pairs_u32(tkhip_ctx* ctx, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout,
+                   size_t n, int end_bit);
+int exclusive_scan_i32(tkhip_ctx* ctx, const int32_t* in, int32_t* out, size_t n);
+
+int upload_direction_tables(tkhip_ctx* ctx);
+void destroy_sppm(tkhip_ctx* ctx);
+
+}  // namespace tkd

@@ -51,3 +51,8 @@ void makeSyntheticScene(Config* config, const std::string& modelDir, int quads, 
 void cameraMatrices(const TkCameraConfig& cam, int width, int height, float c2w[16], float raster2cam[16]);
 
 }  // namespace tk
+
+// The opaque scene handle of the C view (include/tkhost.h).
+struct tkhost_scene {
+    tk::Config config;
+};

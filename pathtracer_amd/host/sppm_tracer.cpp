@@ -1,0 +1,221 @@
+// sppm_tracer.cpp — host-side tracer classes driving the device backend.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include "ray_tracer.h"
+#include "tkhost.h"
+
+namespace tk {
+
+void setHostError(const std::string& e);
+
+RayTracer::RayTracer(int spp, int maxDepth, int numThreads, float russianRoulette)
+    : mNumThreads(numThreads), mMaxDepth(maxDepth), mRussianRoulette(russianRoulette) {
+    // spp rounded up to a power of two (src/core/TkRayTracer.cpp:20-26)
+    spp--;
+    spp |= spp >> 1; spp |= spp >> 2; spp |= spp >> 4; spp |= spp >> 8; spp |= spp >> 16;
+    mSpp = spp + 1;
+}
+
+RayTracer::~RayTracer() {
+    if (mCtx) tkhip_destroy(mCtx);
+}
+
+bool RayTracer::fail(const char* what) {
+    mError = std::string(what) + ": " + tkhip_last_error();
+    fprintf(stderr, "\n[Tracer] %s\n", mError.c_str());
+    return false;
+}
+
+// src/core/TkRayTracer.cpp:36-41
+void RayTracer::setScene(const SceneData* scene) {
+    if (mState != INIT) return;
+    mScene = scene;
+}
+
+// src/core/TkRayTracer.cpp:43-52
+void RayTracer::setCamera(const Camera* cam) {
+    if (mState != INIT && mState != READY) return;
+    mCamera = cam;
+    mWidth = cam->width;
+    mHeight = cam->height;
+    mFrameBuffer.assign(size_t(mWidth) * size_t(mHeight), 0u);
+    mState = READY;
+}
+
+bool RayTracer::uploadScene() {
+    if (!mScene || !mCamera) {
+        mError = "setScene and setCamera must be called before rendering";
+        return false;
+    }
+    if (!mCtx && tkhip_create(mDevice, &mCtx) != 0) return fail("tkhip_create");
+    const SceneData& s = *mScene;
+    if (tkhip_set_scene(mCtx, s.objects.data(), int(s.objects.size()), s.tris.data(), int(s.tris.size()),
+                        s.spheres.data(), int(s.spheres.size()), s.materials.data(), int(s.materials.size()),
+                        s.lights.data(), int(s.lights.size())) != 0)
+        return fail("tkhip_set_scene");
+    if (tkhip_set_camera(mCtx, mCamera->c2w, mCamera->rasterToCamera, mWidth, mHeight) != 0)
+        return fail("tkhip_set_camera");
+    return true;
+}
+
+// src/core/TkRayTracer.cpp:54-73 without the GL blit: advances the render by
+// one step and refreshes the preview buffer.
+void RayTracer::updateScreen() {
+    switch (mState) {
+    case INIT:
+    case READY:
+    case DONE: break;
+    case VISUALIZE: visualize(); break;
+    case RENDERING: rendering(); break;
+    }
+}
+
+void RayTracer::stop() {   // src/core/TkRayTracer.cpp:75-91
+    switch (mState) {
+    case INIT:
+    case READY: break;
+    case VISUALIZE:
+    case RENDERING:
+    case DONE: mState = READY; break;
+    }
+}
+
+void RayTracer::clear() {}   // src/core/TkRayTracer.cpp:93-100 (a no-op there too)
+
+void RayTracer::startVisualizing() {
+    if (mState != READY) return;
+    mState = VISUALIZE;
+}
+
+void RayTracer::startRaytracing() {   // src/core/TkRayTracer.cpp:109-122
+    if (mState != READY) return;
+    std::fill(mFrameBuffer.begin(), mFrameBuffer.end(), 0u);
+    mState = RENDERING;
+}
+
+void RayTracer::saveImage(std::string) {}
+
+// ------------------------------------------------------------------- SPPM
+SppmTracer::SppmTracer(int spp, int maxDepth, int numThreads, float russianRoulette, TkSppmParam param)
+    : RayTracer(spp, maxDepth, numThreads, russianRoulette), mParam(param) {
+    int x = 0, y = 0;
+    while (++x * ++y < param.numRecurse) {}   // src/tracer/TkSppmTracer.cpp:18-20
+    numRecurse = x * y;
+}
+
+// src/tracer/TkSppmTracer.cpp:385-398
+void SppmTracer::startRaytracing() {
+    if (mState != READY) return;
+    curRecurse = 0;
+    mStats.clear();
+    if (mCtx) {   // a fresh context per render keeps the state machine simple
+        tkhip_destroy(mCtx);
+        mCtx = nullptr;
+    }
+    if (!uploadScene()) return;
+    if (tkhip_sppm_begin(mCtx, &mParam, mMaxDepth, mRussianRoulette, mSeed, 0, 1) != 0) {
+        fail("tkhip_sppm_begin");
+        return;
+    }
+    fprintf(stderr, "\r[Tracer] device %d, %dx%d, %d iterations\n", mDevice, mWidth, mHeight, numRecurse);
+    RayTracer::startRaytracing();
+}
+
+bool SppmTracer::resolve(std::vector<uint8_t>* rgb) {
+    rgb->resize(size_t(mWidth) * size_t(mHeight) * 3);
+    if (tkhip_sppm_resolve_rgb8(mCtx, numRecurse, rgb->data()) != 0) return fail("tkhip_sppm_resolve_rgb8");
+    return true;
+}
+
+// One round of the Generate -> Rendering state machine
+// (src/tracer/TkSppmTracer.cpp:43-102), i.e. one SPPM iteration, followed by
+// the tone-mapped preview of the current estimate.
+void SppmTracer::rendering() {
+    if (mState != RENDERING) return;
+    TkIterStats st;
+    memset(&st, 0, sizeof(st));
+    if (tkhip_sppm_iteration(mCtx, curRecurse, &st) != 0) {
+        fail("tkhip_sppm_iteration");
+        mState = READY;
+        return;
+    }
+    mStats.push_back(st);
+    fprintf(stderr, "\r[Tracer] Shoot global photons %lld\n", (long long)st.shoot_global);
+    fprintf(stderr, "\r[Tracer] Shoot caustic photons %lld\n", (long long)st.shoot_caustic);
+    fprintf(stderr, "\r[Tracer] Iteration %d... 100%%  (%.2f ms: photons %.2f, build %.2f, camera %.2f, gather %.2f)\n",
+            curRecurse, st.ms_total, st.ms_photon, st.ms_build, st.ms_camera, st.ms_gather);
+    ++curRecurse;
+    std::vector<uint8_t> rgb;
+    if (resolve(&rgb)) {
+        // preview buffer: RGBA, same row order as the SPPMPixel array (y down)
+        for (int y = 0; y < mHeight; ++y)
+            for (int x = 0; x < mWidth; ++x) {
+                const uint8_t* p = &rgb[(size_t(mHeight - 1 - y) * mWidth + x) * 3];
+                mFrameBuffer[size_t(y) * mWidth + x] = 0xFF000000u | (uint32_t(p[2]) << 16) | (uint32_t(p[1]) << 8) | p[0];
+            }
+    }
+    if (curRecurse >= numRecurse) {
+        fprintf(stderr, "\r[Tracer] Rendering Done!\n");
+        mState = DONE;
+    }
+}
+
+void SppmTracer::saveImage(std::string filename) {
+    if (mState != DONE && mState != RENDERING) return;
+    if (filename.empty()) filename = "binary.ppm";
+    std::vector<uint8_t> rgb;
+    if (!resolve(&rgb)) return;
+    fprintf(stderr, "\n[Tracer] Saving to file: %s... ", filename.c_str());
+    if (tkhost_write_ppm(filename.c_str(), mWidth, mHeight, rgb.data()) == 0) fprintf(stderr, "Done!\n");
+    else fprintf(stderr, "FAILED\n");
+}
+
+// src/tracer/TkSppmTracer.cpp:447-544
+void SppmTracer::render(std::string filename) {
+    startRaytracing();
+    while (mState == RENDERING) rendering();
+    if (mState == DONE) saveImage(filename);
+}
+
+std::unique_ptr<RayTracer> createTracer(const TkTracerConfig& cfg, std::string* error) {
+    std::string type = cfg.type;
+    if (type == "sppm")
+        return std::unique_ptr<RayTracer>(
+            new SppmTracer(cfg.spp, cfg.max_depth, cfg.num_threads, cfg.russian_roulette, cfg.sppm));
+    if (error) *error = "tracer type '" + type + "' has no device path (only 'sppm' is accelerated)";
+    return nullptr;
+}
+
+}  // namespace tk
+
+extern "C" int tkhost_render(tkhost_scene* s, int device, int width, int height, const char* out_ppm, uint64_t seed,
+                             double* seconds_out) {
+    if (!s) {
+        tk::setHostError("tkhost_render: null scene");
+        return -1;
+    }
+    tk::Config& cfg = s->config;
+    int w = width > 0 ? width : cfg.width, h = height > 0 ? height : cfg.height;
+    std::string err;
+    std::unique_ptr<tk::RayTracer> tracer = tk::createTracer(cfg.tracer, &err);
+    if (!tracer) {
+        tk::setHostError(err);
+        return -1;
+    }
+    tk::Camera camera(cfg.camera, w, h);
+    tracer->setDevice(device);
+    tracer->setSeed(seed);
+    tracer->setScene(&cfg.scene);
+    tracer->setCamera(&camera);
+    auto start = std::chrono::system_clock::now();
+    tracer->render(out_ppm ? out_ppm : cfg.outfilename);
+    auto stop = std::chrono::system_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(stop - start).count();
+    if (!tracer->done()) {
+        tk::setHostError(tracer->error().empty() ? "render did not finish" : tracer->error());
+        return -1;
+    }
+    return 0;
+}

@@ -7,10 +7,6 @@
 #include "scene_loader.h"
 #include "tkhost.h"
 
-struct tkhost_scene {
-    tk::Config config;
-};
-
 namespace {
 thread_local std::string g_error;
 }
