@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SPPM iterations per second on cornell_dragon at 1024^2
+(200k global + 50k caustic photons per iteration, kNN k = 100 / 50, 1 camera
+ray per pixel), synthetic: the scene files under assets/ and random-free
+deterministic sampling.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one full SPPM iteration: both photon passes, both KD-tree builds,
+the camera pass with its gathers and the per-pixel update.  With N > 1 (one
+process per GPU under torch.distributed.run) the fixed workload is split over
+the ranks (strong scaling): photon paths and pixel rows are sharded, the
+photon maps are all-gathered over RCCL every iteration.
+
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = "cornell_dragon.scene"
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, GB/s
+
+
+def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
+    """The CPU oracle (a port of the reference algorithm) on a bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    osc = O.OracleScene(scene, width, height)
+    # fair CPU mode: widest-axis KD-tree, near-first BVH with culling, hashed RNG
+    r = O.OracleSppm(osc, param, max_depth, rr, seed, threads=threads, split_mode=1, faithful_bvh=0, rng_cost=0)
+    t0 = time.time()
+    st_p = r.photon_pass(0)
+    t1 = time.time()
+    r.build_maps()
+    t2 = time.time()
+    rows = max(8, height // 32)
+    y0 = height // 2 - rows // 2
+    st_c = r.camera_pass(0, y0, y0 + rows)
+    t3 = time.time()
+    scale = height / rows
+    sec_iter = (t1 - t0) + (t2 - t1) + (t3 - t2) * scale
+    rays = st_p.rays + st_c.rays * scale
+    gathers = (st_c.gathers_global + st_c.gathers_caustic) * scale
+    r.close()
+    osc.close()
+    return {
+        "value": 1.0 / sec_iter, "unit": "iterations/s", "cores": threads, "kind": "port",
+        "sample": (f"CPU oracle, iteration 0: full photon pass ({t1 - t0:.2f}s) + both KD builds ({t2 - t1:.2f}s) + "
+                   f"camera pass on {rows} of {height} rows ({t3 - t2:.2f}s, scaled x{scale:.0f}); widest-axis KD-tree, "
+                   f"near-first culled BVH, hashed RNG (the reference's per-call Mersenne-Twister seeding is not charged)"),
+        "mrays_per_s": rays / sec_iter / 1e6, "gathers_per_s": gathers / sec_iter,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default=WORKLOAD)
+    ap.add_argument("--size", type=int, default=0, help="override the image size of the scene (square)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from pathtracer_amd import _abi
+    from pathtracer_amd import distributed as D
+    from pathtracer_amd.scene import Scene, asset_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+
+    scene = Scene.load(asset_scene(args.scene))
+    W = args.size or scene.width
+    H = args.size or scene.height
+    param = scene.sppm_param()
+    max_depth, rr, seed = scene.tracer.max_depth, scene.tracer.russian_roulette, 0x5EED
+    backend = D.HipBackend(scene, param, max_depth, rr, seed, W, H, rank, world, local_rank)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for it in range(args.warmup):
+        D.iteration(backend, it, world)
+    sync()
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        D.iteration(backend, it, world)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # instrumented iterations after the timed region: counters, per-phase and per-kernel device time
+    acc = None
+    n_inst = 3
+    for it in range(args.warmup + args.steps, args.warmup + args.steps + n_inst):
+        st = _abi.TkIterStats()
+        D.iteration(backend, it, world, st)
+        d = st.as_dict()
+        acc = d if acc is None else {k: acc[k] + d[k] for k in d}
+    sync()
+    vals = torch.tensor([acc["rays"], acc["gathers_global"], acc["gathers_caustic"], acc["gather_photons"],
+                         acc["overflow_global"], acc["overflow_caustic"], acc["global_paths"], acc["caustic_paths"]],
+                        dtype=torch.float64, device=dev)
+    times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"]],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    vals = (vals / n_inst).tolist()
+    times = (times / n_inst).tolist()
+    rays, ng, nc, phot, og, oc, gpaths, cpaths = vals
+    ms_group, ms_photon, ms_build, ms_camera, ms_gather = times
+
+    if rank == 0:
+        its = args.steps / elapsed
+        ms_step = elapsed / args.steps * 1e3
+        # Algorithmic bytes of a gather: 56 B query + 26 B per photon found + 40 B pixel slice.
+        # The grouped kernel finishes the gathers that met fewer than k photons; the others end
+        # with exactly k photons in the per-query kernel and are not charged to it here.
+        k_g, k_c = param.globalSample, param.causticSample
+        done = (ng - og) + (nc - oc)
+        phot_group = phot - k_g * og - k_c * oc
+        bytes_group = 96.0 * done + 26.0 * phot_group
+        achieved = bytes_group / (ms_group * 1e-3) / 1e9 if ms_group > 0 else 0.0
+        out = {
+            "metric": "SPPM iterations/sec", "value": its, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene} {W}x{H}, {param.globalSize} global + {param.causticSize} caustic photons/iter, "
+                                   f"k={k_g}/{k_c}, depth {max_depth}, 1 ray/pixel",
+                       "parallelism": f"photon paths + pixel rows over {world} GPU(s), photon all-gather"},
+            "mrays_per_s": rays / (ms_step * 1e-3) / 1e6,
+            "gathers_per_s": (ng + nc) / (ms_step * 1e-3),
+            "photon_paths_per_s": (gpaths + cpaths) / (ms_step * 1e-3),
+            "phase_ms": {"photon": ms_photon, "kd_build": ms_build, "camera": ms_camera, "gather": ms_gather,
+                         "gather_group_kernel": ms_group},
+            "roofline": {"bound": "hbm", "kernel": "k_gather_group", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches_per_step": 2, "avg_launch_ms": ms_group / 2.0,
+                         "algorithmic_bytes_per_step": bytes_group,
+                         "gathers_finished": done, "gathers_to_selection_kernel": og + oc},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, param, max_depth, rr, seed, args.cpu_threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    backend.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

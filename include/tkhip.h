@@ -120,6 +120,8 @@ typedef struct TkIterStats {
     int64_t gathers_global;   /* radiance_estimate calls on the global map          */
     int64_t gathers_caustic;  /* radiance_estimate calls on the caustic map         */
     int64_t gather_photons;   /* sum of photons found over all gathers              */
+    int64_t overflow_global;  /* global gathers that met >= k photons and went to   */
+    int64_t overflow_caustic; /*   the per-query selection kernel (same, caustic)   */
     float ms_photon;          /* photon passes + compaction                         */
     float ms_build;           /* both KD-tree builds                                */
     float ms_camera;          /* camera paths incl. NEE, without gathers            */

@@ -173,7 +173,7 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
         bld.order.clear();
         bld.max_depth = 0;
         bld.median_only = attempt == 1;
-        bld.depth_limit = max_stack_depth - 12;
+        bld.depth_limit = max_stack_depth - 6;
         bld.nodes.reserve(size_t(n) * 2);
         bld.order.reserve(size_t(n));
         if (attempt == 1) bld.prims = saved;

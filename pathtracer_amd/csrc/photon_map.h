@@ -48,7 +48,8 @@ struct tkhip_map {
     tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
-    float last_group_ms = 0.f;   // duration of the last grouped gather kernel
+    float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)
+    int64_t last_overflow = 0;   // queries the last timed gather handed to the per-query kernel
     tkd::MapView view() const;
 };
 

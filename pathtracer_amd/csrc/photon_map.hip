@@ -667,6 +667,7 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         else launch_wave<8>(m, qv, list, cnt, nq, hint, out);
     };
     m->last_group_ms = 0.f;
+    m->last_overflow = 0;
     if (mode == 1) {
         wave_all(nullptr, nullptr, nq);
         TK_LAUNCH_CHECK();
@@ -708,6 +709,12 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     }
     wave_all(m->overflow.as<int32_t>(), ocount, nq);
     TK_LAUNCH_CHECK();
+    if (timed) {
+        int32_t oc = 0;
+        TK_HIP(hipMemcpyAsync(&oc, ocount, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(hipStreamSynchronize(s));
+        m->last_overflow = oc;
+    }
     return TKHIP_OK;
 }
 

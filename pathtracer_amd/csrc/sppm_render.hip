@@ -22,6 +22,8 @@
 
 namespace tkd {
 
+constexpr int kTailThreshold = 1 << 18;   // live paths at or below which a pass switches to its tail kernel
+
 enum { C_QA = 0, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */ };
 
 struct SppmState {
@@ -126,9 +128,62 @@ __global__ void __launch_bounds__(256) k_photon_emit(PhotonArgs a, int64_t B, in
     if (alive) queue[dst] = (int32_t)i;
 }
 
-// One bounce of every live light path: closest hit, photon store at diffuse
-// surfaces, Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156
-// for the global map, :179-216 for the caustic map).
+// One bounce of a light path: closest hit, photon store at diffuse surfaces,
+// Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156 for the
+// global map, :179-216 for the caustic map).  Returns true while the path lives.
+struct PhotonPath {
+    F3 o, d, power;
+    float ubx, uby;
+    int flags;
+};
+template <int KIND, class STACK>
+TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, STACK stk) {
+    const DScene& sc = a.sc;
+    Hit h = trace_ray<false>(sc, P.o, P.d, 1.7976931348623157e308, stk);
+    if (h.prim < 0) return false;
+    SurfacePoint sp = surface_at(sc, h, P.o, P.d);
+    F3 wo = neg3(P.d);
+    const TkMaterial m = sc.mats[sp.mat];
+    bool diffuse = m.type == TK_DIFFUSE;
+    if (KIND == 0) {
+        if (diffuse) {
+            int c = a.rec_count[slot];
+            int64_t at = (int64_t)slot * a.slots + c;
+            a.stage_pos[at] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
+            a.stage_pow[at] = make_float4(P.power.x, P.power.y, P.power.z, 0.f);
+            a.rec_count[slot] = c + 1;
+        }
+    } else {
+        if (!diffuse) P.flags |= 1;
+        if (diffuse) {
+            if (P.flags & 1) {
+                a.stage_pos[slot] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
+                a.stage_pow[slot] = make_float4(P.power.x, P.power.y, P.power.z, 0.f);
+                a.rec_count[slot] = 1;
+            }
+            return false;
+        }
+    }
+    uint64_t H = halton_index(a, slot);
+    if (photon_rng(a.seed, H, KIND, bounce, 1) > a.rr) return false;
+    F3 wi;
+    float pdf;
+    F3 f = mat_sample_f(m, true, wo, &wi, sp.n, P.ubx, P.uby, &pdf);
+    if (pdf == 0 || isblack(f)) return false;
+    P.power = divs3(scale3(mul3(P.power, f), absdot3(wi, sp.n)), pdf * a.rr);
+    P.o = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
+    P.d = wi;
+    return bounce + 1 < a.depth;
+}
+TKD PhotonPath load_photon_path(const PhotonArgs& a, int slot) {
+    float4 so = a.st.o[slot], sd = a.st.d[slot], sw = a.st.w[slot];
+    PhotonPath P;
+    P.o = mk3(so.x, so.y, so.z); P.d = mk3(sd.x, sd.y, sd.z); P.power = mk3(sw.x, sw.y, sw.z);
+    P.ubx = so.w; P.uby = sd.w; P.flags = __float_as_int(sw.w);
+    return P;
+}
+
+// Wavefront stage: one bounce of every live path, survivors compacted into qout.
 template <int KIND>
 __global__ void __launch_bounds__(256) k_photon_bounce(PhotonArgs a, int bounce, const int32_t* qin,
                                                        const int32_t* count_in, int32_t* qout, int32_t* count_out,
@@ -141,58 +196,39 @@ __global__ void __launch_bounds__(256) k_photon_bounce(PhotonArgs a, int bounce,
     int slot = 0;
     if (j < n) {
         slot = qin[j];
-        const DScene& sc = a.sc;
-        float4 so = a.st.o[slot], sd = a.st.d[slot], sw = a.st.w[slot];
-        F3 o = mk3(so.x, so.y, so.z), d = mk3(sd.x, sd.y, sd.z), power = mk3(sw.x, sw.y, sw.z);
-        int flags = __float_as_int(sw.w);
-        Hit h = trace_ray<false>(sc, o, d, 1.7976931348623157e308, stk);
-        if (h.prim >= 0) {
-            SurfacePoint sp = surface_at(sc, h, o, d);
-            F3 wo = neg3(d);
-            const TkMaterial m = sc.mats[sp.mat];
-            bool diffuse = m.type == TK_DIFFUSE;
-            bool stop = false;
-            if (KIND == 0) {
-                if (diffuse) {
-                    int c = a.rec_count[slot];
-                    int64_t at = (int64_t)slot * a.slots + c;
-                    a.stage_pos[at] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
-                    a.stage_pow[at] = make_float4(power.x, power.y, power.z, 0.f);
-                    a.rec_count[slot] = c + 1;
-                }
-            } else {
-                if (!diffuse) flags |= 1;
-                if (diffuse) {
-                    if (flags & 1) {
-                        a.stage_pos[slot] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
-                        a.stage_pow[slot] = make_float4(power.x, power.y, power.z, 0.f);
-                        a.rec_count[slot] = 1;
-                    }
-                    stop = true;
-                }
-            }
-            uint64_t H = halton_index(a, slot);
-            if (!stop && !(photon_rng(a.seed, H, KIND, bounce, 1) > a.rr)) {
-                F3 wi;
-                float pdf;
-                F3 f = mat_sample_f(m, true, wo, &wi, sp.n, so.w, sd.w, &pdf);
-                if (!(pdf == 0 || isblack(f))) {
-                    power = divs3(scale3(mul3(power, f), absdot3(wi, sp.n)), pdf * a.rr);
-                    F3 no = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
-                    if (bounce + 1 < a.depth) {
-                        a.st.o[slot] = make_float4(no.x, no.y, no.z, so.w);
-                        a.st.d[slot] = make_float4(wi.x, wi.y, wi.z, sd.w);
-                        a.st.w[slot] = make_float4(power.x, power.y, power.z, __int_as_float(flags));
-                        go_on = true;
-                    }
-                }
-            }
+        PhotonPath P = load_photon_path(a, slot);
+        go_on = photon_step<KIND>(a, slot, bounce, P, stk);
+        if (go_on) {
+            a.st.o[slot] = make_float4(P.o.x, P.o.y, P.o.z, P.ubx);
+            a.st.d[slot] = make_float4(P.d.x, P.d.y, P.d.z, P.uby);
+            a.st.w[slot] = make_float4(P.power.x, P.power.y, P.power.z, __int_as_float(P.flags));
         }
     }
     int dst = wave_append(count_out, go_on);
     if (go_on) qout[dst] = slot;
     unsigned long long traced = __ballot(j < n);
     if ((threadIdx.x & 63) == 0 && traced) atomicAdd(rays, (unsigned long long)__popcll(traced));
+}
+
+// Tail stage: once few paths are left a launch per bounce costs more than the
+// bounces themselves; each lane then walks its own path to the end.
+constexpr int kTailBlock = 64;
+template <int KIND>
+__global__ void __launch_bounds__(kTailBlock) k_photon_tail(PhotonArgs a, int bounce0, const int32_t* qin,
+                                                            const int32_t* count_in, unsigned long long* rays) {
+    __shared__ int s_stack[kStackDepth * kTailBlock];
+    LdsStackT<kTailBlock> stk{&s_stack[threadIdx.x]};
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int n = *count_in;
+    if (j >= n) return;
+    const int slot = qin[j];
+    PhotonPath P = load_photon_path(a, slot);
+    int traced = 0;
+    for (int b = bounce0; b < a.depth; ++b) {
+        ++traced;
+        if (!photon_step<KIND>(a, slot, b, P, stk)) break;
+    }
+    atomicAdd(rays, (unsigned long long)traced);
 }
 
 // Appends the staged photons of the batch in path order behind the `base`
@@ -269,9 +305,110 @@ TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp
     qbase[3 * qcap + dst] = make_float4(m.R[0] * kInvPi, m.R[1] * kInvPi, m.R[2] * kInvPi, 0.f);
 }
 
-// One bounce of every live camera path (loop body of traceTile,
+// One bounce of a camera path (loop body of traceTile,
 // src/tracer/TkSppmTracer.cpp:306-371, with Scene::uniformSampleOneLight,
-// src/core/Scene.cpp:43-61, inlined).
+// src/core/Scene.cpp:43-61, inlined).  Gather queries are reported through
+// want_cq / want_gq together with the surface they belong to.
+struct CameraPath {
+    F3 o, d, coef;
+    int flags;     // bit0: only specular surfaces so far; bits 1..: sampler dimension
+};
+struct CameraStepOut {
+    bool want_cq, want_gq;
+    SurfacePoint sp;
+    F3 coef;
+    TkMaterial m;
+    int nrays;
+};
+template <class STACK>
+TKD bool camera_step(const CameraArgs& a, int x, int y, int pixel, int bounce, CameraPath& P, CameraStepOut& out,
+                     STACK stk) {
+    const DScene& sc = a.sc;
+    out.want_cq = out.want_gq = false;
+    out.nrays = 1;
+    bool has_glossy = P.flags & 1;
+    Sampler sm = make_sampler(a, x, y, P.flags >> 1);
+    Hit h = trace_ray<false>(sc, P.o, P.d, 1.7976931348623157e308, stk);
+    if (h.prim < 0) return false;
+    const SurfacePoint sp = surface_at(sc, h, P.o, P.d);
+    const TkMaterial m = sc.mats[sp.mat];
+    const bool diffuse = m.type == TK_DIFFUSE;
+    const F3 wo = neg3(P.d);
+    const F3 coef = P.coef;
+    F3 Ld = mk3(0, 0, 0);
+    if (has_glossy && sp.light >= 0) Ld = add3(Ld, mul3(coef, light_L(sc.lights[sp.light], sp.n, wo)));
+    if ((has_glossy || !diffuse) && sc.n_lights > 0) {
+        // uniformSampleOneLight: the sampler dimensions advance for every material
+        int nl = sc.n_lights;
+        int li = (int)(sampler_get1d(sm) * nl);
+        li = li > nl - 1 ? nl - 1 : li;
+        float pdf_choice = 1.0f / nl;
+        float ulx, uly;
+        sampler_get2d(sm, &ulx, &uly);
+        float u0 = sampler_get1d(sm);
+        if (diffuse) {   // f() of mirror and glass is black: nothing to add, no shadow ray needed
+            const DLight L = sc.lights[li];
+            float pd, tmp;
+            int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, u0, &pd);
+            LightPoint lp = tri_sample(sc, L.tri_first + idx, ulx, uly, &tmp);
+            F3 wv = sub3(lp.p, sp.p);
+            float dist2 = dot3(wv, wv);
+            if (dist2 == 0) tmp = 0;
+            else { F3 wn = normalize3(wv); tmp *= dist2 / absdot3(lp.n, neg3(wn)); }
+            float pdf_light = pd * tmp;
+            if (!(pdf_light == 0 || dist2 == 0)) {
+                F3 ws = normalize3(wv);
+                F3 Li = light_L(L, lp.n, neg3(ws));
+                if (!isblack(Li)) {
+                    // Intersection::spawnRayTo(other), src/Intersection.hpp:40-48
+                    F3 so2 = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
+                    F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(so2, lp.p));
+                    Hit sh = trace_ray<true>(sc, so2, sub3(target, so2), (double)kOneMinusEps, stk);
+                    ++out.nrays;
+                    if (sh.prim < 0) {
+                        F3 f = mat_f(m, sp.wo, ws, sp.n);
+                        Ld = add3(Ld, mul3(coef, divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice)));
+                    }
+                }
+            }
+        }
+    }
+    if (!isblack(Ld)) {
+        a.planes[pixel] += Ld.x;
+        a.planes[a.n_pixels + pixel] += Ld.y;
+        a.planes[2 * a.n_pixels + pixel] += Ld.z;
+    }
+    if (diffuse) {
+        out.sp = sp; out.coef = coef; out.m = m;
+        if (has_glossy && a.caustic_stored > 0) out.want_cq = true;
+        if (!has_glossy) { out.want_gq = true; return false; }
+    }
+    has_glossy = has_glossy && !diffuse;
+    float ux, uy;
+    sampler_get2d(sm, &ux, &uy);
+    F3 wi;
+    float pdf;
+    F3 f = mat_sample_f(m, false, wo, &wi, sp.n, ux, uy, &pdf);
+    if (isblack(f) || pdf == 0 || !(bounce + 1 < a.depth)) return false;
+    P.coef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
+    P.o = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
+    P.d = wi;
+    P.flags = (has_glossy ? 1 : 0) | (sm.dim << 1);
+    return true;
+}
+TKD void camera_emit_queries(const CameraArgs& a, int32_t* counters, const CameraStepOut& o, int pixel) {
+    int dc = wave_append(&counters[C_NCQ], o.want_cq);
+    if (o.want_cq) emit_query(a.cq, a.qcap, dc, o.sp, o.coef, o.m, a.planes[11 * a.n_pixels + pixel], pixel);
+    int dg = wave_append(&counters[C_NGQ], o.want_gq);
+    if (o.want_gq) emit_query(a.gq, a.qcap, dg, o.sp, o.coef, o.m, a.planes[12 * a.n_pixels + pixel], pixel);
+}
+TKD void count_rays(int32_t* counters, int nrays) {
+    float wr = (float)nrays;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
+    if ((threadIdx.x & 63) == 0 && wr > 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
+}
+
 __global__ void __launch_bounds__(256) k_camera_bounce(CameraArgs a, int bounce, const int32_t* qin,
                                                        const int32_t* count_in, int32_t* qout, int32_t* counters,
                                                        int out_counter) {
@@ -279,106 +416,60 @@ __global__ void __launch_bounds__(256) k_camera_bounce(CameraArgs a, int bounce,
     LdsStack stk{&s_stack[threadIdx.x]};
     const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int n = *count_in;
-    bool go_on = false, want_gq = false, want_cq = false;
-    int slot = 0, pixel = 0, nrays = 0;
-    SurfacePoint sp{};
-    F3 coef = mk3(0, 0, 0);
-    TkMaterial m{};
-    const DScene& sc = a.sc;
+    bool go_on = false;
+    int slot = 0, pixel = 0;
+    CameraStepOut so{};
     if (j < n) {
         slot = qin[j];
         const int W = a.cam.w;
         const int y = a.rows[slot / W], x = slot % W;
         pixel = x + y * W;
-        float4 so = a.st.o[slot], sd = a.st.d[slot], sw = a.st.w[slot];
-        F3 o = mk3(so.x, so.y, so.z), d = mk3(sd.x, sd.y, sd.z);
-        coef = mk3(sw.x, sw.y, sw.z);
-        int flags = __float_as_int(sw.w);
-        bool has_glossy = flags & 1;
-        Sampler sm = make_sampler(a, x, y, flags >> 1);
-        Hit h = trace_ray<false>(sc, o, d, 1.7976931348623157e308, stk);
-        ++nrays;
-        if (h.prim >= 0) {
-            sp = surface_at(sc, h, o, d);
-            m = sc.mats[sp.mat];
-            const bool diffuse = m.type == TK_DIFFUSE;
-            const F3 wo = neg3(d);
-            F3 Ld = mk3(0, 0, 0);
-            if (has_glossy && sp.light >= 0) Ld = add3(Ld, mul3(coef, light_L(sc.lights[sp.light], sp.n, wo)));
-            if ((has_glossy || !diffuse) && sc.n_lights > 0) {
-                // uniformSampleOneLight: the sampler dimensions advance for every material
-                int nl = sc.n_lights;
-                int li = (int)(sampler_get1d(sm) * nl);
-                li = li > nl - 1 ? nl - 1 : li;
-                float pdf_choice = 1.0f / nl;
-                float ulx, uly;
-                sampler_get2d(sm, &ulx, &uly);
-                float u0 = sampler_get1d(sm);
-                if (diffuse) {   // f() of mirror and glass is black: nothing to add, no shadow ray needed
-                    const DLight L = sc.lights[li];
-                    float pd, tmp;
-                    int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, u0, &pd);
-                    LightPoint lp = tri_sample(sc, L.tri_first + idx, ulx, uly, &tmp);
-                    F3 wv = sub3(lp.p, sp.p);
-                    float dist2 = dot3(wv, wv);
-                    if (dist2 == 0) tmp = 0;
-                    else { F3 wn = normalize3(wv); tmp *= dist2 / absdot3(lp.n, neg3(wn)); }
-                    float pdf_light = pd * tmp;
-                    if (!(pdf_light == 0 || dist2 == 0)) {
-                        F3 ws = normalize3(wv);
-                        F3 Li = light_L(L, lp.n, neg3(ws));
-                        if (!isblack(Li)) {
-                            // Intersection::spawnRayTo(other), src/Intersection.hpp:40-48
-                            F3 so2 = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
-                            F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(so2, lp.p));
-                            Hit sh = trace_ray<true>(sc, so2, sub3(target, so2), (double)kOneMinusEps, stk);
-                            ++nrays;
-                            if (sh.prim < 0) {
-                                F3 f = mat_f(m, sp.wo, ws, sp.n);
-                                Ld = add3(Ld, mul3(coef, divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice)));
-                            }
-                        }
-                    }
-                }
-            }
-            if (!isblack(Ld)) {
-                a.planes[pixel] += Ld.x;
-                a.planes[a.n_pixels + pixel] += Ld.y;
-                a.planes[2 * a.n_pixels + pixel] += Ld.z;
-            }
-            bool end_path = false;
-            if (diffuse) {
-                if (has_glossy && a.caustic_stored > 0) want_cq = true;
-                if (!has_glossy) { want_gq = true; end_path = true; }
-            }
-            if (!end_path) {
-                has_glossy = has_glossy && !diffuse;
-                float ux, uy;
-                sampler_get2d(sm, &ux, &uy);
-                F3 wi;
-                float pdf;
-                F3 f = mat_sample_f(m, false, wo, &wi, sp.n, ux, uy, &pdf);
-                if (!(isblack(f) || pdf == 0) && bounce + 1 < a.depth) {
-                    F3 ncoef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
-                    F3 no = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
-                    a.st.o[slot] = make_float4(no.x, no.y, no.z, 0.f);
-                    a.st.d[slot] = make_float4(wi.x, wi.y, wi.z, 0.f);
-                    a.st.w[slot] = make_float4(ncoef.x, ncoef.y, ncoef.z, __int_as_float((has_glossy ? 1 : 0) | (sm.dim << 1)));
-                    go_on = true;
-                }
-            }
+        float4 po = a.st.o[slot], pd = a.st.d[slot], pw = a.st.w[slot];
+        CameraPath P;
+        P.o = mk3(po.x, po.y, po.z); P.d = mk3(pd.x, pd.y, pd.z); P.coef = mk3(pw.x, pw.y, pw.z);
+        P.flags = __float_as_int(pw.w);
+        go_on = camera_step(a, x, y, pixel, bounce, P, so, stk);
+        if (go_on) {
+            a.st.o[slot] = make_float4(P.o.x, P.o.y, P.o.z, 0.f);
+            a.st.d[slot] = make_float4(P.d.x, P.d.y, P.d.z, 0.f);
+            a.st.w[slot] = make_float4(P.coef.x, P.coef.y, P.coef.z, __int_as_float(P.flags));
         }
     }
-    int dc = wave_append(&counters[C_NCQ], want_cq);
-    if (want_cq) emit_query(a.cq, a.qcap, dc, sp, coef, m, a.planes[11 * a.n_pixels + pixel], pixel);
-    int dg = wave_append(&counters[C_NGQ], want_gq);
-    if (want_gq) emit_query(a.gq, a.qcap, dg, sp, coef, m, a.planes[12 * a.n_pixels + pixel], pixel);
+    camera_emit_queries(a, counters, so, pixel);
     int dst = wave_append(&counters[out_counter], go_on);
     if (go_on) qout[dst] = slot;
-    float wr = (float)nrays;
-    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
-    if ((threadIdx.x & 63) == 0 && wr > 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
+    count_rays(counters, so.nrays);
+}
+
+// Tail stage of the camera pass: the few paths still bouncing between specular
+// surfaces are walked to their end by one lane each.
+__global__ void __launch_bounds__(kTailBlock) k_camera_tail(CameraArgs a, int bounce0, const int32_t* qin,
+                                                            const int32_t* count_in, int32_t* counters) {
+    __shared__ int s_stack[kStackDepth * kTailBlock];
+    LdsStackT<kTailBlock> stk{&s_stack[threadIdx.x]};
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int n = *count_in;
+    bool alive = j < n;
+    int slot = 0, pixel = 0, x = 0, y = 0, nrays = 0;
+    CameraPath P{};
+    if (alive) {
+        slot = qin[j];
+        const int W = a.cam.w;
+        y = a.rows[slot / W]; x = slot % W;
+        pixel = x + y * W;
+        float4 po = a.st.o[slot], pd = a.st.d[slot], pw = a.st.w[slot];
+        P.o = mk3(po.x, po.y, po.z); P.d = mk3(pd.x, pd.y, pd.z); P.coef = mk3(pw.x, pw.y, pw.z);
+        P.flags = __float_as_int(pw.w);
+    }
+    for (int b = bounce0; b < a.depth && __any(alive); ++b) {
+        CameraStepOut so{};
+        if (alive) {
+            alive = camera_step(a, x, y, pixel, b, P, so, stk);
+            nrays += so.nrays;
+        }
+        camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
+    }
+    count_rays(counters, nrays);
 }
 
 // Final colour + gamma + RGB8, rows bottom-up (src/tracer/TkSppmTracer.cpp:514-529)
@@ -495,19 +586,25 @@ static int photon_pass_kind(tkhip_ctx* ctx, TkIterStats* st) {
         TK_LAUNCH_CHECK();
         int64_t live_bound = B;
         int ca = C_QA, cb = C_QB;
+        unsigned long long* rays = reinterpret_cast<unsigned long long*>(&counters[C_RAYS]);
         for (int b = 0; b < depth; ++b) {
             TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
-            k_photon_bounce<KIND><<<divup(live_bound, 256), 256, 0, stream>>>(
-                a, b, qa, &counters[ca], qb, &counters[cb], reinterpret_cast<unsigned long long*>(&counters[C_RAYS]));
+            k_photon_bounce<KIND><<<divup(live_bound, 256), 256, 0, stream>>>(a, b, qa, &counters[ca], qb, &counters[cb], rays);
             TK_LAUNCH_CHECK();
             std::swap(qa, qb);
             std::swap(ca, cb);
-            if (b == 1 || b == 3 || b == 7 || b == 15 || b == 31) {
-                // shrink the launch to the live paths now and then, and stop early when none is left
+            if (b + 1 < depth && (b == 1 || b == 3 || b == 7 || b == 15 || b == 31)) {
+                // look at the live count now and then: stop when no path is left, hand a short
+                // queue to the tail kernel, otherwise shrink the next launches
                 int32_t live = 0;
                 TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
                 TK_HIP(hipStreamSynchronize(stream));
                 if (live == 0) break;
+                if (live <= kTailThreshold) {
+                    k_photon_tail<KIND><<<divup(live, kTailBlock), kTailBlock, 0, stream>>>(a, b + 1, qa, &counters[ca], rays);
+                    TK_LAUNCH_CHECK();
+                    break;
+                }
                 live_bound = live;
             }
         }
@@ -721,11 +818,16 @@ int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
             TK_LAUNCH_CHECK();
             std::swap(qa, qb);
             std::swap(ca, cb);
-            if (b == 1 || b == 3 || b == 7 || b == 15 || b == 31) {
+            if (b + 1 < s->max_depth && (b == 1 || b == 3 || b == 7 || b == 15 || b == 31)) {
                 int32_t live = 0;
                 TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
                 TK_HIP(hipStreamSynchronize(stream));
                 if (live == 0) break;
+                if (live <= kTailThreshold) {
+                    k_camera_tail<<<divup(live, kTailBlock), kTailBlock, 0, stream>>>(a, b + 1, qa, &counters[ca], counters);
+                    TK_LAUNCH_CHECK();
+                    break;
+                }
                 live_bound = live;
             }
         }
@@ -749,6 +851,7 @@ int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
             out.photon_sum = reinterpret_cast<unsigned long long*>(&counters[C_PHOT]);
             TK_TRY(map_gather_device(s->map[which], nq, qv, out, 0, st != nullptr));
             group_ms += s->map[which]->last_group_ms;
+            if (st) (which == 0 ? st->overflow_global : st->overflow_caustic) += s->map[which]->last_overflow;
         }
         if (st) {
             st->ms_gather += tg.stop();

@@ -154,7 +154,7 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
                    TKHIP_E_ARG, "material %d: unsupported type %d", m, materials[m].type);
 
     HostBvh bvh;
-    build_bvh(tris, n_tris, spheres, n_spheres, 4, kStackDepth, &bvh);
+    build_bvh(tris, n_tris, spheres, n_spheres, kMaxLeaf, kStackDepth, &bvh);
     TK_REQUIRE(bvh.max_depth < kStackDepth - 1, TKHIP_E_LIMIT, "scene BVH depth %d exceeds the traversal stack", bvh.max_depth);
 
     const size_t nprim = (size_t)n_tris + n_spheres;

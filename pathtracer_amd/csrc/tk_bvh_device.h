@@ -13,16 +13,19 @@
 
 namespace tkd {
 
-constexpr int kStackDepth = 40;      // per-lane entries; the builder bounds the tree depth
+constexpr int kStackDepth = 32;      // per-lane entries; the builder bounds the tree depth
+constexpr int kMaxLeaf = 2;          // primitives per BVH leaf
 constexpr int kTraceBlock = 256;     // threads per block of every kernel that traces
 
-// LDS stack: entry e of lane t lives at stack[e * kTraceBlock + t] so that the
-// 64 lanes of a wave touch 64 consecutive banks.
-struct LdsStack {
+// LDS stack: entry e of thread t lives at stack[e * STRIDE + t] (STRIDE = block
+// size) so that the 64 lanes of a wave touch 64 consecutive banks.
+template <int STRIDE>
+struct LdsStackT {
     int* base;
-    TKD void push(int sp, int v) { base[sp * kTraceBlock] = v; }
-    TKD int pop(int sp) { return base[sp * kTraceBlock]; }
+    TKD void push(int sp, int v) { base[sp * STRIDE] = v; }
+    TKD int pop(int sp) { return base[sp * STRIDE]; }
 };
+using LdsStack = LdsStackT<kTraceBlock>;
 
 struct Hit {
     int prim;        // original primitive id, -1 = miss
@@ -105,19 +108,35 @@ TKD bool sphere_hit_t(float4 sph, F3 o, F3 d, double tmax, float* thit) {
 }
 
 // Triangle::intersect (src/Triangle.cpp:15-37): fp32 products, fp64 scalars.
+// The fp64 division only runs for rays that pass a conservative fp32 screen:
+// u = un/det and v = vn/det can only lie in [0,1] (and t be positive) when the
+// numerators have the sign of det and do not exceed it by more than rounding,
+// so anything the screen drops is also dropped by the exact test below.
 TKD bool tri_hit(const TriIsect& T, F3 o, F3 d, double tmax, double* tout, double* uout, double* vout) {
     F3 e1 = ld3(T.e1), e2 = ld3(T.e2);
     F3 pvec = cross3(d, e2);
-    double det = (double)dot3(e1, pvec);
-    if (fabs(det) < (double)kEps) return false;
-    double det_inv = 1. / det;
+    float detf = dot3(e1, pvec);
+    float adet = fabsf(detf);
+    if (adet < kEps) return false;
     F3 tvec = sub3(o, ld3(T.v0));
-    double u = (double)dot3(tvec, pvec) * det_inv;
-    if (u < 0 || u > 1) return false;
+    float unf = dot3(tvec, pvec);
+    float sgn = detf < 0.f ? -1.f : 1.f;
+    float us = unf * sgn;                       // u * |det|
+    const float slack = adet * 1.0e-5f;
+    if (us < 0.f || us > adet + slack) return false;
     F3 qvec = cross3(tvec, e1);
-    double v = (double)dot3(d, qvec) * det_inv;
+    float vnf = dot3(d, qvec);
+    float vs = vnf * sgn;                       // v * |det|
+    if (vs < 0.f || us + vs > adet + slack) return false;
+    float tnf = dot3(e2, qvec);
+    if (tnf * sgn <= 0.f) return false;         // t <= 0
+    double det = (double)detf;
+    double det_inv = 1. / det;
+    double u = (double)unf * det_inv;
+    if (u < 0 || u > 1) return false;
+    double v = (double)vnf * det_inv;
     if (v < 0 || u + v > 1) return false;
-    double t = (double)dot3(e2, qvec) * det_inv;
+    double t = (double)tnf * det_inv;
     if (t > 0 && t < tmax) { *tout = t; *uout = u; *vout = v; return true; }
     return false;
 }
@@ -136,27 +155,36 @@ TKD bool box_hit(const float* bmin, const float* bmax, F3 o, F3 dinv, float tmax
     return tn <= tf && tf > 0 && tn < tmax;
 }
 
+TKD void prim_test(const DScene& sc, const TriIsect& T, F3 o, F3 d, Hit* h) {
+    if (T.prim < sc.n_tris) {
+        double t, u, v;
+        if (tri_hit(T, o, d, h->t, &t, &u, &v)) { h->t = t; h->u = u; h->v = v; h->prim = T.prim; }
+    } else {
+        float th;
+        if (sphere_hit_t(sc.spheres[T.prim - sc.n_tris], o, d, h->t, &th)) { h->t = (double)th; h->prim = T.prim; }
+    }
+}
+
+// A leaf holds at most kMaxLeaf primitives; their records are fetched together
+// (independent loads in flight) before any of them is tested.
 template <bool ANY_HIT>
 TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int64_t* nprims) {
     int first = enc >> 3, count = (enc & 7) + 1;
-    for (int i = 0; i < count; ++i) {
+    const TriIsect T0 = sc.tri_isect[first];
+    const TriIsect T1 = sc.tri_isect[first + (count > 1 ? 1 : 0)];
+    prim_test(sc, T0, o, d, h);
+    if (count > 1) prim_test(sc, T1, o, d, h);
+    for (int i = 2; i < count; ++i) {
         const TriIsect T = sc.tri_isect[first + i];
-        if (nprims) ++*nprims;
-        if (T.prim < sc.n_tris) {
-            double t, u, v;
-            if (tri_hit(T, o, d, h->t, &t, &u, &v)) { h->t = t; h->u = u; h->v = v; h->prim = T.prim; }
-        } else {
-            float th;
-            if (sphere_hit_t(sc.spheres[T.prim - sc.n_tris], o, d, h->t, &th)) { h->t = (double)th; h->prim = T.prim; }
-        }
+        prim_test(sc, T, o, d, h);
     }
 }
 
 // Closest hit (ANY_HIT = false) or occlusion (ANY_HIT = true: stops at the
 // first hit below tmax, enough for the boolean Scene::intersectP answers,
 // src/core/Scene.cpp:27-31).
-template <bool ANY_HIT>
-TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, LdsStack st) {
+template <bool ANY_HIT, class STACK>
+TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, STACK st) {
     Hit h;
     h.prim = -1; h.t = tmax; h.u = 0; h.v = 0;
     if (sc.n_nodes == 0) {

@@ -1,0 +1,152 @@
+"""One SPPM render over `world` processes, one GPU each (torch.distributed).
+
+The reference is a single process (shared-memory threads, src/Threads.cpp);
+the path shards along its two natural seams:
+
+  photon phase : rank r traces the light paths whose Halton index is r modulo
+                 world and fills a quota of size/world photons per map;
+  exchange     : the per-rank photon arrays are all-gathered (RCCL over xGMI
+                 with the "nccl" backend) and the shoot counters all-reduced,
+                 so every rank holds both complete maps and builds both trees;
+  camera phase : rank r owns the pixel rows y with (y // 8) % world == r and
+                 keeps their SPPMPixel state for the whole render;
+  end          : the pixel planes are gathered to rank 0, which resolves.
+
+The exchange logic is independent of what computes the phases: `HipBackend`
+drives libtkhip on a GPU; the CPU tests plug the oracle in to check the
+sharding arithmetic with the gloo backend.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _abi
+from ._abi import check
+
+ROW_BLOCK = 8
+
+
+def row_owner(y, world):
+    return (y // ROW_BLOCK) % world
+
+
+def quota(size, rank, world):
+    return size // world + (1 if rank < size % world else 0)
+
+
+class HipBackend:
+    """Phases of an iteration on one GPU through the C ABI; buffers are torch CUDA tensors."""
+
+    def __init__(self, scene, param, max_depth, rr, seed, width, height, rank, world, device):
+        from .tracer import SppmTracer
+        self.tracer = SppmTracer(1, max_depth, 0, rr, param, device=device, seed=seed, rank=rank, world=world)
+        self.tracer.setScene(scene)
+        self.tracer.setCamera(width, height)
+        self.tracer.startRaytracing()
+        self.param, self.rank, self.world = param, rank, world
+        self.width, self.height = width, height
+        self.dev = torch.device("cuda", device)
+        self.lib = self.tracer.ctx.lib
+        self.h = self.tracer.ctx.h
+        self.quota = [quota(param.globalSize, rank, world), quota(param.causticSize, rank, world)]
+        self.max_quota = [quota(param.globalSize, 0, world), quota(param.causticSize, 0, world)]
+        self.num_recurse = self.tracer.num_recurse
+
+    def photon_pass(self, it, stats=None):
+        self.tracer.photon_pass(it, stats)
+
+    def export_local(self, which):
+        cap = max(self.max_quota[which], 1)
+        pos = torch.zeros((cap, 3), dtype=torch.float32, device=self.dev)
+        power = torch.zeros((cap, 3), dtype=torch.float32, device=self.dev)
+        direction = torch.zeros((cap,), dtype=torch.int16, device=self.dev)
+        n, shot = C.c_int64(), C.c_int64()
+        torch.cuda.synchronize(self.dev)
+        check(self.lib, self.lib.tkhip_sppm_export_local_photons(self.h, which, pos.data_ptr(), power.data_ptr(),
+                                                                 direction.data_ptr(), cap, C.byref(n), C.byref(shot)),
+              "tkhip_sppm_export_local_photons")
+        return pos, power, direction, n.value, shot.value
+
+    def set_map(self, which, pos, power, direction, n, shot_total):
+        torch.cuda.synchronize(self.dev)
+        check(self.lib, self.lib.tkhip_sppm_set_map_photons(self.h, which, pos.data_ptr(), power.data_ptr(),
+                                                            direction.data_ptr(), n, shot_total),
+              "tkhip_sppm_set_map_photons")
+
+    def build_maps(self, stats=None):
+        self.tracer.build_maps(stats)
+
+    def camera_pass(self, it, stats=None):
+        self.tracer.camera_pass(it, stats)
+
+    def export_planes(self):
+        planes = torch.empty((13, self.height, self.width), dtype=torch.float32, device=self.dev)
+        check(self.lib, self.lib.tkhip_sppm_export_planes(self.h, planes.data_ptr()), "tkhip_sppm_export_planes")
+        return planes
+
+    def import_planes(self, planes):
+        planes = planes.contiguous()
+        torch.cuda.synchronize(self.dev)
+        check(self.lib, self.lib.tkhip_sppm_import_planes(self.h, planes.data_ptr()), "tkhip_sppm_import_planes")
+
+    def resolve(self):
+        return self.tracer.resolve(self.num_recurse)
+
+    def close(self):
+        self.tracer.close()
+
+
+def exchange_photons(backend, which, world):
+    """All-gather of one map's photons + all-reduce of its shot counter.  Returns (n_total, shot_total)."""
+    pos, power, direction, n, shot = backend.export_local(which)
+    if world == 1:
+        backend.set_map(which, pos, power, direction, n, shot)
+        return n, shot
+    meta = torch.tensor([n, shot], dtype=torch.int64, device=pos.device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    counts = [int(m[0]) for m in metas]
+    shot_total = sum(int(m[1]) for m in metas)
+    gathered = []
+    for t in (pos, power, direction):
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous())
+        gathered.append(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).contiguous())
+    n_total = sum(counts)
+    backend.set_map(which, gathered[0], gathered[1], gathered[2], n_total, shot_total)
+    return n_total, shot_total
+
+
+def iteration(backend, it, world, stats=None):
+    """photon pass -> exchange -> tree builds -> camera pass, for every rank in lockstep."""
+    backend.photon_pass(it, stats)
+    totals = [exchange_photons(backend, which, world) for which in (0, 1)]
+    backend.build_maps(stats)
+    backend.camera_pass(it, stats)
+    return totals
+
+
+def gather_planes(backend, rank, world, height):
+    """Merges the row-sharded SPPMPixel planes on rank 0 (other ranks return None)."""
+    planes = backend.export_planes()
+    if world == 1:
+        return planes
+    parts = [torch.empty_like(planes) for _ in range(world)] if rank == 0 else None
+    dist.gather(planes, parts, dst=0)
+    if rank != 0:
+        return None
+    owner = torch.tensor([row_owner(y, world) for y in range(height)], device=planes.device)
+    merged = planes.clone()
+    for r in range(1, world):
+        rows = owner == r
+        merged[:, rows, :] = parts[r][:, rows, :]
+    return merged
+
+
+def init_process_group_from_env(backend="nccl"):
+    """RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run."""
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
