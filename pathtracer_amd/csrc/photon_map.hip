@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
 }
 
 // ---------------------------------------- grouped kernel (64 queries per wave)
-// Queries arrive sorted along a Morton curve, so the 64 of a wave are
+// Queries arrive sorted along a Hilbert curve, so the 64 of a wave are
 // neighbours in space.  The wave walks the tree once with the union of their
 // search boxes; every photon of an overlapping leaf is broadcast from the lane
 // that loaded it and tested by all 64 queries at once.  A query that meets
@@ -448,9 +448,14 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         const float hiy = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.y + rr : -INFINITY));
         const float hiz = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.z + rr : -INFINITY));
         const float r2lo = Q.r2 * 0.999999f, r2hi = Q.r2 * 1.000001f;
+        // a wave whose queries are spread out (ends of the curve, isolated surfaces) would test far
+        // more photons than its queries need: it hands all of them to the per-query kernel instead
+        const float own_sum = uniform_f(wave_sum(Q.r2 > 0.f ? 8.f * rr * rr * rr : 0.f));
+        const int n_live = __popcll(__ballot(Q.r2 > 0.f));
+        const bool spread = n_live > 0 && (hix - lox) * (hiy - loy) * (hiz - loz) * (float)n_live > 64.f * own_sum;
         int cnt = 0;
         float sx = 0, sy = 0, sz = 0;
-        if (mv.n > 0 && lox <= hix) {
+        if (mv.n > 0 && lox <= hix && !spread) {
             // stackless depth-first walk of the implicit tree (heap numbering)
             int node = 1;
             do {
@@ -493,7 +498,7 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
                 node = (node + 1) >> __builtin_ctz((unsigned)(node + 1));
             } while (node != 1);
         }
-        const bool over = valid && cnt >= k;
+        const bool over = valid && (cnt >= k || (spread && Q.r2 > 0.f));
         if (valid && !over) finish_query(out, q, Q, cnt, Q.r2 > 0.f ? Q.r2 : qv.q0[q].w, mk3(sx, sy, sz));
         int dst = wave_append(overflow_count, over);
         if (over) overflow[dst] = (int32_t)q;
@@ -503,23 +508,42 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
 }
 
-// Morton key of the query position inside the scene/photon bounds, 10 bits per axis.
-TKD uint32_t spread10(uint32_t v) {
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+// Position of a query along a 3-D Hilbert curve through the photon bounds
+// (10 bits per axis, Skilling's transpose form).  Unlike a Morton curve a
+// Hilbert curve has no jumps: consecutive queries in this order are always
+// neighbours in space, so the search boxes of the 64 queries of a wave overlap.
+TKD uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t X[3] = {x, y, z};
+    const uint32_t M = 1u << 9;
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        uint32_t P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    uint32_t key = 0;
+#pragma unroll
+    for (int b = 9; b >= 0; --b) {
+        key = (key << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+    }
+    return key;
 }
-__global__ void k_query_morton(QueryView qv, int64_t nq, F3 bmin, F3 binv, uint32_t* keys, uint32_t* vals) {
+__global__ void k_query_curve(QueryView qv, int64_t nq, F3 bmin, F3 binv, uint32_t* keys, uint32_t* vals) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nq) return;
     float4 a = qv.q0[i];
     float fx = fminf(fmaxf((a.x - bmin.x) * binv.x, 0.f), 1023.f);
     float fy = fminf(fmaxf((a.y - bmin.y) * binv.y, 0.f), 1023.f);
     float fz = fminf(fmaxf((a.z - bmin.z) * binv.z, 0.f), 1023.f);
-    keys[i] = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+    keys[i] = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz);
     vals[i] = (uint32_t)i;
 }
 
@@ -620,7 +644,7 @@ int map_build(tkhip_map* m) {
         k_inner_boxes<<<divup(1 << level, B), B, 0, s>>>(m->node_box.as<float4>(), level);
     TK_LAUNCH_CHECK();
     if (idx != m->idx_a.as<uint32_t>()) std::swap(m->idx_a, m->idx_b);   // idx_a always holds the final order
-    // the root box orders the queries of later gathers along a Morton curve
+    // the root box orders the queries of later gathers along a space-filling curve
     float4 rb[2];
     TK_HIP(hipMemcpyAsync(rb, m->node_box.as<float4>() + 2, sizeof(rb), hipMemcpyDeviceToHost, s));
     TK_HIP(hipStreamSynchronize(s));
@@ -678,12 +702,12 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     TK_TRY(m->q_vals_a.ensure((size_t)nq * 4));
     TK_TRY(m->q_order.ensure((size_t)nq * 4));
     TK_TRY(m->overflow.ensure((size_t)nq * 4));
-    // Morton order inside the root box of the tree
+    // Hilbert order inside the root box of the tree
     F3 bmin{m->scene_min[0], m->scene_min[1], m->scene_min[2]};
     float ex = m->scene_max[0] - m->scene_min[0], ey = m->scene_max[1] - m->scene_min[1],
           ez = m->scene_max[2] - m->scene_min[2];
     F3 binv{ex > 0 ? 1023.f / ex : 0.f, ey > 0 ? 1023.f / ey : 0.f, ez > 0 ? 1023.f / ez : 0.f};
-    k_query_morton<<<divup(nq, 256), 256, 0, s>>>(qv, nq, bmin, binv, m->q_keys_a.as<uint32_t>(), m->q_vals_a.as<uint32_t>());
+    k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, bmin, binv, m->q_keys_a.as<uint32_t>(), m->q_vals_a.as<uint32_t>());
     TK_LAUNCH_CHECK();
     TK_TRY(sort_pairs_u32(ctx, m->q_keys_a.as<uint32_t>(), m->q_keys_b.as<uint32_t>(), m->q_vals_a.as<uint32_t>(),
                           m->q_order.as<uint32_t>(), (size_t)nq, 30));

@@ -99,23 +99,23 @@ class HipBackend:
 
 
 def exchange_photons(backend, which, world):
-    """All-gather of one map's photons + all-reduce of its shot counter.  Returns (n_total, shot_total)."""
-    pos, power, direction, n, shot = backend.export_local(which)
+    """All-gather of one map's photons and sum of its shot counters.  Returns (n_total, shot_total)."""
     if world == 1:
-        backend.set_map(which, pos, power, direction, n, shot)
-        return n, shot
+        return None   # a single rank installs its own photons at the end of its photon pass
+    pos, power, direction, n, shot = backend.export_local(which)
     meta = torch.tensor([n, shot], dtype=torch.int64, device=pos.device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
     counts = [int(m[0]) for m in metas]
     shot_total = sum(int(m[1]) for m in metas)
     gathered = []
-    for t in (pos, power, direction):
+    # the two direction bytes travel as int32: neither RCCL nor gloo reduces or gathers int16
+    for t in (pos, power, direction.to(torch.int32)):
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t.contiguous())
         gathered.append(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).contiguous())
     n_total = sum(counts)
-    backend.set_map(which, gathered[0], gathered[1], gathered[2], n_total, shot_total)
+    backend.set_map(which, gathered[0], gathered[1], gathered[2].to(torch.int16).contiguous(), n_total, shot_total)
     return n_total, shot_total
 
 

@@ -1,0 +1,201 @@
+"""CPU tests of the host side: the .scene / OBJ / PLY loader, camera matrices,
+and that the C-ABI libraries load and export every declared symbol.  No
+compute call is made here (there is no GPU on the CPU test box)."""
+import ctypes as C
+import math
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import _abi
+from pathtracer_amd.scene import ASSETS, Scene, asset_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tk(?:hip|host)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_tkhip_exports_every_declared_symbol():
+    names = _declared("tkhip.h")
+    assert len(names) >= 25
+    lib = _abi.load_tkhip()
+    for n in names:
+        assert hasattr(lib, n), n
+    # the Python binding table and the header agree
+    assert sorted(_abi.TKHIP_SYMBOLS) == names
+    assert lib.tkhip_version().startswith(b"tkhip")
+
+
+def test_tkhost_exports_every_declared_symbol():
+    names = _declared("tkhost.h")
+    lib = _abi.load_tkhost()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_abi.TKHOST_SYMBOLS) == names
+
+
+def test_abi_struct_sizes_match_the_header():
+    assert C.sizeof(_abi.TkTriangle) == 36 and C.sizeof(_abi.TkSphere) == 16
+    assert C.sizeof(_abi.TkMaterial) == 36 and C.sizeof(_abi.TkLight) == 20 and C.sizeof(_abi.TkObject) == 20
+    assert C.sizeof(_abi.TkSppmParam) == 24 and C.sizeof(_abi.TkSPPMPixel) == 52
+    assert C.sizeof(_abi.TkIterStats) == 12 * 8 + 6 * 4
+
+
+def test_argument_errors_without_touching_the_gpu():
+    lib = _abi.load_tkhip()
+    assert lib.tkhip_set_scene(None, None, 0, None, 0, None, 0, None, 0, None, 0) == -1      # TKHIP_E_ARG
+    assert b"null context" in lib.tkhip_last_error()
+    assert lib.tkhip_sppm_iteration(None, 0, None) == -1
+    assert lib.tkhip_map_gather(None, 0, None, None, None, None, None, None, None, None, None, 0) == -1
+    assert lib.tkhip_sppm_counters(None, None, None, None) == -2                             # TKHIP_E_STATE
+
+
+def test_product_has_no_oracle_dependency():
+    """The product libraries must not link or load the oracle."""
+    for name in ("libtkhip.so", "libtkhost.so", "raytracer"):
+        out = subprocess.run(["ldd", os.path.join(_abi.LIB_DIR, name)], capture_output=True, text=True).stdout
+        assert "oracle" not in out
+    pat = re.compile(r"liboracle|orc_[a-z]|sppm_oracle|oracle_py|from oracle|import oracle")
+    for root, _, files in os.walk(os.path.join(ROOT, "pathtracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                assert not pat.search(open(os.path.join(root, f), errors="ignore").read()), f
+
+
+# ------------------------------------------------------------------ scenes
+def test_benchmark_scenes_load(box_scene, sphere_scene, dragon_scene):
+    assert (box_scene.n_triangles, box_scene.n_spheres, box_scene.n_objects) == (32, 0, 6)
+    assert (sphere_scene.n_triangles, sphere_scene.n_spheres, sphere_scene.n_objects) == (12, 2, 6)
+    assert (dragon_scene.n_triangles, dragon_scene.n_spheres) == (100012, 0)
+    assert (dragon_scene.width, dragon_scene.height) == (1024, 1024)
+    for sc in (box_scene, sphere_scene, dragon_scene):
+        assert sc.n_lights == 1 and sc.tracer.type == b"sppm"
+        assert sc.tracer.max_depth == 20 and sc.tracer.russian_roulette == pytest.approx(0.8)
+        p = sc.tracer.sppm
+        assert (p.numRecurse, p.globalSize, p.globalSample, p.causticSample) == (16, 200000, 100, 50)
+        assert p.radius2 == pytest.approx(0.08)
+        light = sc.lights[0]
+        ob = sc.objects[light.object]
+        assert ob.kind == 0 and ob.count == 2 and ob.light == 0 and light.two_sided == 0
+    assert box_scene.tracer.sppm.causticSize == 0 and sphere_scene.tracer.sppm.causticSize == 50000
+    # mesh transform: position(-2.2,-2.2,0), scale 0.008 -> the box spans [-2.2, 2.2482] x [-2.2, 2.1904] x [0, 4.4736]
+    t = box_scene.triangles_np().reshape(-1, 3)
+    assert np.allclose(t.min(0), [-2.2, -2.2, 0.0], atol=1e-5)
+    assert np.allclose(t.max(0), [-2.2 + 556 * 0.008, -2.2 + 548.8 * 0.008, 559.2 * 0.008], atol=1e-4)
+    # glass of the sphere scene
+    m = [sphere_scene.materials[i] for i in range(sphere_scene.n_materials)]
+    glass = [x for x in m if x.type == _abi.TK_GLASS][0]
+    assert glass.etaA == 1.0 and glass.etaB == pytest.approx(1.75496)
+    assert sum(1 for x in m if x.type == _abi.TK_MIRROR) == 1
+
+
+def test_scene_defaults_and_errors(tmp_path):
+    lib = _abi.load_tkhost()
+    obj = tmp_path / "tri.obj"
+    obj.write_text("# one quad, one triangle with negative indices\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\n"
+                   "f 1/1/1 2/2/2 3/3/3 4/4/4\nf -4 -3 -2\n")
+    scene = tmp_path / "s.scene"
+    scene.write_text(f"""<?xml version="1.0"?>
+<!-- defaults: 784x784, spp 16, depth 32, threads 4, roulette 0.8 -->
+<scene filename='out.ppm'>
+  <camera><fov v="40"/><near_clip v="0.1"/><far_clip v="100"/><position x="0" y="1.5707963" z="5"/></camera>
+  <tracer type="sppm"><recurse i="5"/><gsize i="10"/><gsample i="3"/><csize i="0"/><csample i="2"/><radius v="0.5"/></tracer>
+  <material name="m" type="diffuse"/>
+  <mesh name="q" filename="{obj}"><position x="1" y="2" z="3"/><scale x="2" y="2" z="2"/></mesh>
+  <light name="l" mesh="q"><color r="1" g="2" b="3"/></light>
+  <object type="light" material="m" light="l" mesh="q"/>
+  <object type="sphere" material="m"><position x="0" y="0" z="0"/><radius v="0.5"/></object>
+</scene>""")
+    s = Scene.load(str(scene))
+    assert (s.width, s.height, s.windows, s.outfilename) == (784, 784, 0, "out.ppm")
+    assert (s.tracer.spp, s.tracer.max_depth, s.tracer.num_threads) == (16, 32, 4)
+    assert s.tracer.russian_roulette == pytest.approx(0.8)
+    assert s.n_triangles == 3 and s.n_spheres == 1          # quad fanned into two + one triangle
+    t = s.triangles_np()
+    assert np.allclose(t[0], [[1, 2, 3], [3, 2, 3], [3, 4, 3]])      # scale 2 then translate
+    assert np.allclose(t[1], [[1, 2, 3], [3, 4, 3], [1, 4, 3]])
+    assert list(s.materials[0].R) == [1, 1, 1]               # white default
+    # errors: unknown material, missing required element, malformed XML, missing file
+    bad = tmp_path / "bad.scene"
+    for text, needle in [
+        (scene.read_text().replace('material="m" light', 'material="zz" light'), "No such material"),
+        (scene.read_text().replace('<recurse i="5"/>', ''), "no 'recurse' defined"),
+        (scene.read_text().replace("</scene>", ""), "parse error"),
+        (scene.read_text().replace(str(obj), str(tmp_path / "nope.obj")), "cannot open"),
+        (scene.read_text().replace('type="diffuse"', 'type="plastic"'), "not supported"),
+    ]:
+        bad.write_text(text)
+        h = C.c_void_p()
+        assert lib.tkhost_load_scene(os.fsencode(str(bad)), C.byref(h)) != 0
+        assert needle in lib.tkhost_last_error().decode()
+
+
+def test_ply_loader_ascii_and_binary(tmp_path):
+    verts = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)]
+    ascii_ply = tmp_path / "a.ply"
+    ascii_ply.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                         "element face 2\nproperty list uchar int vertex_indices\nend_header\n" +
+                         "".join(f"{x} {y} {z}\n" for x, y, z in verts) + "4 0 1 2 3\n3 0 2 3\n")
+    bin_ply = tmp_path / "b.ply"
+    body = b"".join(struct.pack("<fff", *v) for v in verts) + struct.pack("<Biiii", 4, 0, 1, 2, 3) + struct.pack("<Biii", 3, 0, 2, 3)
+    bin_ply.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\n"
+                        b"property float z\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n" + body)
+    tris = []
+    for f in (ascii_ply, bin_ply):
+        sc = tmp_path / "p.scene"
+        sc.write_text(f"""<scene><camera><fov v="40"/><near_clip v="0.1"/><far_clip v="100"/><position x="0" y="1" z="5"/></camera>
+<tracer type="sppm"><recurse i="1"/><gsize i="1"/><gsample i="1"/><csize i="0"/><csample i="1"/><radius v="1"/></tracer>
+<material name="m" type="mirror"/><mesh name="q" filename="{f}"><position x="0" y="0" z="0"/><scale x="1" y="1" z="1"/></mesh>
+<light name="l" mesh="q"><color r="1" g="1" b="1"/></light><object type="light" material="m" light="l" mesh="q"/></scene>""")
+        tris.append(Scene.load(str(sc)).triangles_np())
+    assert tris[0].shape == (3, 3, 3) and (tris[0] == tris[1]).all()
+    assert np.allclose(tris[0][1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])   # quad split 0-1-2, 0-2-3
+
+
+def test_synthetic_scene_generator():
+    s = Scene.synthetic(16)
+    assert s.n_triangles == 4 + 2 + 2 + 2 + 16 * 16 * 2 and s.n_spheres == 2
+    t = s.triangles_np()[-512:]
+    n = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+    assert (n[:, 1] > 0).all()                                # height field faces up
+    assert abs(t[:, :, 1].mean() + 2.2) < 0.1 and t[:, :, 1].max() < -2.2 + 0.17
+    s2 = Scene.synthetic(16)
+    assert (s2.triangles_np() == s.triangles_np()).all()      # deterministic
+
+
+def test_camera_matrices(sphere_scene):
+    c2w, r2c = sphere_scene.camera_matrices(512, 512)
+    c2w = c2w.reshape(4, 4); r2c = r2c.reshape(4, 4)
+    assert np.allclose(c2w[:3, 3], [0, 0, -6.5], atol=1e-5)           # eye
+    assert np.allclose(c2w[:3, 2], [0, 0, -1], atol=1e-6)             # camera +z points away from the target
+    assert np.allclose(c2w[:3, :3] @ c2w[:3, :3].T, np.eye(3), atol=1e-6)
+    # the raster centre maps onto the optical axis, the raster edge to tan(fov/2) at unit depth
+    def cam(px, py):
+        v = r2c @ np.array([px, py, 0, 1], np.float32)
+        return v[:3] / v[3]
+    centre, edge = cam(256, 256), cam(512, 256)
+    assert abs(centre[0]) < 1e-6 and abs(centre[1]) < 1e-6 and centre[2] < 0
+    assert abs(edge[0] / edge[2]) == pytest.approx(math.tan(math.radians(20)), rel=1e-4)
+
+
+def test_cli_reports_usage_and_bad_scene(tmp_path):
+    exe = os.path.join(_abi.LIB_DIR, "raytracer")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert "Please input the scene file" in out.stderr
+    out = subprocess.run([exe, str(tmp_path / "missing.scene")], capture_output=True, text=True)
+    assert out.returncode == 1 and "cannot open" in out.stdout
+
+
+def test_assets_present():
+    for f in ("scenes/cornell_box.scene", "scenes/cornell_sphere.scene", "scenes/cornell_dragon.scene",
+              "scenes/cornell_dragon_2m.scene", "models/dragon.obj", "models/cornellbox/light.obj"):
+        assert os.path.exists(os.path.join(ASSETS, f)), f
+    assert asset_scene("cornell_box.scene").endswith("cornell_box.scene")

@@ -1,0 +1,387 @@
+"""CPU tests of the oracle (test infrastructure): hand-derived known answers,
+internal consistency and the committed golden vectors.
+
+The reference has no tests or fixtures of its own, so nothing here comes from
+it: known answers are worked out from the cited formulas.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from pathtracer_amd import _abi
+from tests.conftest import golden, make_photons, make_queries
+
+L = O.lib()
+
+
+# ---------------------------------------------------------------- Halton / sampler
+def test_radical_inverse_known_values():
+    # base 2 (dim 0): bit reversal; base 3 (dim 1): digit reversal
+    assert L.orc_radical_inverse(0, 0) == 0.0
+    assert L.orc_radical_inverse(0, 1) == 0.5
+    assert L.orc_radical_inverse(0, 2) == 0.25
+    assert L.orc_radical_inverse(0, 3) == 0.75
+    assert L.orc_radical_inverse(0, 6) == 0.375
+    assert abs(L.orc_radical_inverse(1, 1) - 1 / 3) < 1e-7
+    assert abs(L.orc_radical_inverse(1, 5) - (2 / 3 + 1 / 9)) < 1e-6     # 5 = 12_3 -> 0.21_3
+    assert abs(L.orc_radical_inverse(2, 7) - (2 / 5 + 1 / 25)) < 1e-6    # 7 = 12_5 -> 0.21_5
+    assert L.orc_radical_inverse(6, 17) == pytest.approx(1 / 289, rel=1e-6)
+    # clamp to 1 - eps (src/core/TkLowdiscrepancy.h:31)
+    assert L.orc_radical_inverse(0, (1 << 40) - 1) <= np.float32(float.fromhex("0x1.fffffep-1"))
+
+
+def test_radical_inverse_golden():
+    g = golden("radical_inverse.npz")
+    v = np.array([L.orc_radical_inverse(int(d), int(i)) for d, i in zip(g["dim"], g["index"])], np.float32)
+    assert (v == g["value"]).all()
+
+
+def test_permutation_element_is_a_permutation():
+    for l in (1, 4, 9, 16, 25, 64):
+        for p in (0, 1, 0xdeadbeef, 123456789):
+            vals = sorted(L.orc_permutation_element(i, l, p) for i in range(l))
+            assert vals == list(range(l))
+
+
+def test_sampler_golden():
+    g = golden("sampler.npz")
+    hv = np.array([L.orc_hash_pixel(*map(int, r)) for r in g["pixel_dim_seed"]], np.uint64)
+    assert (hv == g["hash"]).all()
+    pe = np.array([L.orc_permutation_element(int(a), int(b), int(c)) for a, b, c in g["perm_in"]], np.int32)
+    assert (pe == g["perm"]).all()
+
+
+def test_rng_is_uniform_and_deterministic():
+    a = np.array([L.orc_rng_u01(0x5EED, i, 3, 7) for i in range(20000)], np.float32)
+    assert a.min() >= 0 and a.max() < 1
+    assert abs(a.mean() - 0.5) < 0.01 and abs(a.var() - 1 / 12) < 0.005
+    assert L.orc_rng_u01(1, 2, 3, 4) == L.orc_rng_u01(1, 2, 3, 4)
+    assert L.orc_rng_u01(1, 2, 3, 4) != L.orc_rng_u01(1, 2, 3, 5)
+
+
+# ---------------------------------------------------------------- direction bytes
+def test_direction_tables_and_roundtrip():
+    g = golden("direction_tables.npz")
+    tabs = [np.empty(256, np.float32) for _ in range(4)]
+    L.orc_direction_tables(*[O.fp(t) for t in tabs])
+    for t, key in zip(tabs, ("cos_theta", "sin_theta", "cos_phi", "sin_phi")):
+        assert (t == g[key]).all()
+    ct, st, cp, sp = tabs
+    assert ct[0] == 1.0 and abs(ct[255] + 1.0) < 1e-6 and abs(st[0]) < 1e-7
+    assert cp[0] == 1.0 and abs(cp[255] - 1.0) < 1e-5           # phi index 255 wraps to 2*pi
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=(2000, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    th, ph = C.c_uint8(), C.c_uint8()
+    worst = 0.0
+    for w in v:
+        L.orc_encode_direction(O.fp(np.ascontiguousarray(w)), C.byref(th), C.byref(ph))
+        d = np.array([st[th.value] * cp[ph.value], st[th.value] * sp[ph.value], ct[th.value]])
+        worst = max(worst, math.degrees(math.acos(min(1.0, float(d @ w)))))
+    assert worst < 2.5   # two bytes: about 0.7 deg in theta, 1.4 deg in phi
+    # negative azimuth wraps by +255 (src/tracer/TkSppmTracer.cpp:137-138)
+    L.orc_encode_direction(O.fp(np.array([0.6, -0.8, 0.0], np.float32)), C.byref(th), C.byref(ph))
+    assert th.value == 127 and ph.value == int(255 * math.atan2(-0.8, 0.6) / (2 * math.pi)) + 255
+    # acos of a z slightly above one is NaN in the reference; the oracle clamps
+    L.orc_encode_direction(O.fp(np.array([0.0, 0.0, 1.0000001], np.float32)), C.byref(th), C.byref(ph))
+    assert th.value == 255
+
+
+# ---------------------------------------------------------------- kNN
+def _map_from(g):
+    m = O.OracleMap(len(g["pos"]), int(g["k"]))
+    m.store(g["pos"], g["power"], g["theta"], g["phi"])
+    return m
+
+
+@pytest.mark.parametrize("name", ["knn_surface.npz", "knn_small_k50.npz"])
+@pytest.mark.parametrize("split_mode", [0, 1])
+def test_knn_golden_and_tree_shape_independence(name, split_mode):
+    g = golden(name)
+    m = _map_from(g)
+    m.build(split_mode)
+    flux, found, r2o, idx = m.gather(g["qp"], g["qn"], g["qwo"], g["qR"], g["r2"])
+    assert (found == g["found"]).all() and (idx == g["idx"]).all() and (r2o == g["r2out"]).all()
+    np.testing.assert_allclose(flux, g["flux"], rtol=1e-5, atol=1e-12)
+    hist = m.split_histogram()
+    if split_mode == 0:
+        # the reference never updates its bbox, so every interior node splits on z
+        assert hist[0] == 0 and hist[1] == 0 and hist[2] > 0
+    else:
+        assert hist[0] > 0 and hist[1] > 0 and hist[2] > 0
+    m.close()
+
+
+def test_knn_brute_matches_traversal_on_tie_free_data():
+    rng = np.random.default_rng(11)
+    pos, power, th, ph = make_photons(rng, 3000, surface=False)
+    qp, qn, qwo, qR, r2 = make_queries(rng, 200, radius2=(0.3, 2.0, 1e-4))
+    m = O.OracleMap(3000, 25)
+    m.store(pos, power, th, ph)
+    m.build(0)
+    a = m.gather(qp, qn, qwo, qR, r2)
+    b = m.gather(qp, qn, qwo, qR, r2, brute=True)
+    assert (a[1] == b[1]).all() and (a[3] == b[3]).all() and (a[2] == b[2]).all()
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=1e-12)
+    # returned radius: unchanged when fewer than k were found, else the k-th distance
+    less = a[1] < 25
+    assert (a[2][less] == r2[less]).all() and (a[2][~less] < r2[~less]).all()
+    m.close()
+
+
+def test_knn_ties_follow_the_index_rule():
+    g = golden("knn_ties.npz")
+    m = _map_from(g)
+    flux, found, r2o, idx = m.gather(g["qp"], g["qn"], g["qwo"], g["qR"], g["r2"], brute=True)
+    assert (idx == g["idx"]).all() and (found == g["found"]).all() and (r2o == g["r2out"]).all()
+    # strict '<': a photon exactly at the search radius is never taken
+    pos, qp, r2 = g["pos"], g["qp"], g["r2"]
+    for q in range(len(qp)):
+        d2 = ((pos - qp[q]) ** 2).sum(1).astype(np.float32)
+        sel = idx[q][idx[q] >= 0]
+        assert (d2[sel] < r2[q]).all()
+        # among equal distances the lower index wins
+        if found[q] == int(g["k"]):
+            kth = d2[sel].max()
+            outside_ties = np.setdiff1d(np.nonzero(d2 == kth)[0], sel)
+            inside_ties = sel[d2[sel] == kth]
+            if len(outside_ties) and len(inside_ties):
+                assert inside_ties.max() < outside_ties.min()
+    m.close()
+
+
+def test_empty_map_and_zero_radius():
+    m = O.OracleMap(10, 5)
+    m.build(0)
+    qp, qn, qwo, qR, r2 = make_queries(np.random.default_rng(0), 4)
+    flux, found, r2o, idx = m.gather(qp, qn, qwo, qR, r2)
+    assert (found == 0).all() and (flux == 0).all() and (r2o == r2).all() and (idx == -1).all()
+    m.close()
+
+
+# ---------------------------------------------------------------- pixel update / resolve
+def test_pixel_update_rules_by_hand():
+    # first touch: radius, count and flux are taken as they come (src/tracer/TkSppmTracer.cpp:346-351)
+    flux = np.zeros((3, 3), np.float32); photons = np.zeros(3, np.float32); rad = np.full(3, 0.08, np.float32)
+    lind = np.array([[1, 2, 3]] * 3, np.float32); found = np.array([100, 0, 7], np.int32)
+    r2ret = np.array([0.02, 0.08, 0.08], np.float32)
+    L.orc_pixel_update(3, O.fp(flux), O.fp(photons), O.fp(rad), O.fp(lind), O.ip(found), O.fp(r2ret))
+    assert (photons == [100, 0, 7]).all() and (rad == np.float32([0.02, 0.08, 0.08])).all() and (flux == lind).all()
+    # steady state: N' = N + 0.7 M, R'^2 = R^2 N'/(N+M), tau' = (tau + phi) R'^2/R^2
+    flux = np.array([[10, 20, 30]], np.float32); photons = np.array([100], np.float32); rad = np.array([0.02], np.float32)
+    lind = np.array([[1, 1, 1]], np.float32); found = np.array([50], np.int32); r2ret = np.array([0.02], np.float32)
+    L.orc_pixel_update(1, O.fp(flux), O.fp(photons), O.fp(rad), O.fp(lind), O.ip(found), O.fp(r2ret))
+    assert photons[0] == np.float32(135.0)
+    assert rad[0] == pytest.approx(0.02 * 135 / 150, rel=1e-6)
+    np.testing.assert_allclose(flux[0], np.array([11, 21, 31]) * (135 / 150), rtol=1e-6)
+    # M = 0 with history: nothing changes but the flux is rescaled by 1
+    flux = np.array([[4, 5, 6]], np.float32); photons = np.array([10], np.float32); rad = np.array([0.05], np.float32)
+    L.orc_pixel_update(1, O.fp(flux), O.fp(photons), O.fp(rad), O.fp(np.zeros((1, 3), np.float32)),
+                       O.ip(np.zeros(1, np.int32)), O.fp(rad.copy()))
+    assert photons[0] == 10 and rad[0] == np.float32(0.05) and (flux[0] == [4, 5, 6]).all()
+
+
+def test_pixel_update_golden():
+    g = golden("pixel_update.npz")
+    f, p, r = g["flux"].copy(), g["photons"].copy(), g["radius2"].copy()
+    L.orc_pixel_update(len(p), O.fp(f), O.fp(p), O.fp(r), O.fp(g["lindir"]), O.ip(g["found"]), O.fp(g["r2ret"]))
+    assert (f == g["flux_out"]).all() and (p == g["photons_out"]).all() and (r == g["radius2_out"]).all()
+
+
+def test_resolve_formula_and_row_flip():
+    w, h = 2, 2
+    px = (_abi.TkSPPMPixel * 4)()
+    for i in range(4):
+        px[i].causticRadius2 = px[i].globalRadius2 = 0.05
+    px[0].Ld[0] = 4 * 0.25           # top-left pixel: Ld/numRecurse = 0.25 -> 255 * 0.25^0.6 = 110.99 -> 110
+    px[3].globalFlux[1] = math.pi * 0.05 * 1000 * 0.5   # bottom-right: 0.5 in green
+    out = np.zeros((h, w, 3), np.uint8)
+    L.orc_resolve_rgb8(px, w, h, 4, 1000, 0, 0, O.bp(out))
+    assert out[h - 1, 0, 0] == int(255 * 0.25 ** 0.6)      # rows are written bottom-up
+    assert out[0, 1, 1] in (int(255 * 0.5 ** 0.6), int(255 * 0.5 ** 0.6) - 1)
+    assert out[0, 0].sum() == 0
+
+
+# ---------------------------------------------------------------- geometry
+def _single_triangle_scene():
+    tri = (_abi.TkTriangle * 1)()
+    tri[0].v0[:] = [0, 0, 0]; tri[0].v1[:] = [1, 0, 0]; tri[0].v2[:] = [0, 1, 0]
+    sph = (_abi.TkSphere * 1)()
+    sph[0].center[:] = [0, 0, 5]; sph[0].radius = 1.0
+    mat = (_abi.TkMaterial * 1)()
+    mat[0].type = _abi.TK_DIFFUSE
+    obj = (_abi.TkObject * 2)()
+    obj[0].kind, obj[0].first, obj[0].count, obj[0].material, obj[0].light = 0, 0, 1, 0, -1
+    obj[1].kind, obj[1].first, obj[1].count, obj[1].material, obj[1].light = 1, 0, 1, 0, -1
+    h = L.orc_scene_create(obj, 2, tri, 1, sph, 1, mat, 1, None, 0)
+    return h, (tri, sph, mat, obj)
+
+
+def test_triangle_and_sphere_hits_by_hand():
+    h, keep = _single_triangle_scene()
+    # Directions avoid exact +0 components: the reference slab test takes `dir > 0` as "positive"
+    # (src/BVH.cpp:249), so a +0 component with 1/0 = +inf makes tMin = +inf and the box is missed
+    # (src/Bounds3.hpp:102-111).  The oracle keeps that behaviour; it is checked at the end.
+    e = 1e-4
+    org = np.array([[0.25, 0.25, -2], [0.6, 0.6, -2], [0, 0, 10], [0, 0, 5], [0.25, 0.25, -2]], np.float32)
+    d = np.array([[e, e, 1], [e, e, 1], [-e, -e, -1], [1, e, e], [e, e, -1]], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    n = len(org)
+    prim = np.empty(n, np.int32); t = np.empty(n, np.float32)
+    p = np.empty((n, 3), np.float32); nrm = np.empty((n, 3), np.float32); perr = np.empty((n, 3), np.float32)
+    for faithful in (0, 1):
+        L.orc_trace_rays(h, n, O.fp(org), O.fp(d), None, O.ip(prim), O.fp(t), O.fp(p), O.fp(nrm), O.fp(perr), faithful)
+        assert prim.tolist() == [0, 1, 1, 1, -1]
+        assert t[0] == pytest.approx(2.0, rel=1e-6) and np.allclose(p[0], [0.2502, 0.2502, 0], atol=1e-6)
+        assert np.allclose(nrm[0], [0, 0, 1])                 # geometric normal e1 x e2, not flipped towards the ray
+        assert t[1] == pytest.approx(7 - math.sqrt(1 - 0.72), rel=1e-3)   # misses the triangle (u+v > 1), hits the sphere front
+        assert t[2] == pytest.approx(4.0, rel=1e-4) and np.allclose(nrm[2], [0, 0, 1], atol=2e-3)
+        assert t[3] == pytest.approx(1.0, rel=1e-4)          # from the centre: the far root
+        assert (perr[:4] >= 0).all() and perr[0].max() < 1e-5
+    # the +0 quirk: an axis-aligned ray with +0 components finds nothing
+    org0 = np.array([[0.25, 0.25, -2]], np.float32); d0 = np.array([[0, 0, 1]], np.float32)
+    L.orc_trace_rays(h, 1, O.fp(org0), O.fp(d0), None, O.ip(prim), O.fp(t), None, None, None, 1)
+    assert prim[0] == -1
+    L.orc_scene_destroy(h)
+
+
+def test_ray_hits_golden(sphere_scene, box_scene):
+    for name, sc in (("cornell_sphere", sphere_scene), ("cornell_box", box_scene)):
+        g = golden(f"rays_{name}.npz")
+        osc = O.OracleScene(sc, 512, 512)
+        org, d = osc.camera_rays(g["raster"])
+        assert (org == g["org"]).all() and (d == g["dir"]).all()
+        for faithful in (0, 1):
+            prim, t, p, nrm, perr = osc.trace(g["org"], g["dir"], faithful=faithful)
+            assert (prim == g["prim"]).all() and (t == g["t"]).all() and (p == g["p"]).all()
+            prim2, t2, p2, n2, e2 = osc.trace(g["org2"], g["dir2"], faithful=faithful)
+            assert (prim2 == g["prim2"]).all() and (t2 == g["t2"]).all()
+        osc.close()
+
+
+def test_camera_centre_ray_points_into_the_box(sphere_scene):
+    osc = O.OracleScene(sphere_scene, 512, 512)
+    org, d = osc.camera_rays(np.array([[256, 256]], np.float32))
+    assert np.allclose(org[0], [0, 0, -6.5], atol=1e-5)       # theta=-pi, phi=pi/2, r=6.5
+    assert np.allclose(d[0], [0, 0, 1], atol=1e-5)
+    # raster y grows downwards: the top row looks up (+y) or down depending on the projection sign;
+    # check symmetry instead of a sign convention
+    _, dt = osc.camera_rays(np.array([[256, 0], [256, 512]], np.float32))
+    assert np.allclose(dt[0, 1], -dt[1, 1], atol=1e-6) and abs(dt[0, 1]) == pytest.approx(math.sin(math.radians(20)), rel=1e-4)
+    osc.close()
+
+
+# ---------------------------------------------------------------- materials
+def _mat(kind, eta=1.5):
+    m = _abi.TkMaterial()
+    m.type = kind
+    m.R[:] = [0.5, 0.6, 0.7]; m.T[:] = [1, 1, 1]; m.etaA = 1.0; m.etaB = eta
+    return m
+
+
+def _sample_f(m, mode, wo, nrm, u):
+    wo, nrm, u = O.f32(wo), O.f32(nrm), O.f32(u)
+    n = len(wo)
+    wi = np.empty((n, 3), np.float32); f = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32)
+    L.orc_sample_f(C.byref(m), mode, n, O.fp(wo), O.fp(nrm), O.fp(u), O.fp(wi), O.fp(f), O.fp(pdf))
+    return wi, f, pdf
+
+
+def test_materials_by_hand():
+    nrm = np.array([[0, 0, 1]], np.float32)
+    wo = np.array([[0.6, 0.0, 0.8]], np.float32)
+    # mirror: wi is wo reflected about N, f = R / |cos|, pdf 1 (src/core/Material.cpp:90-95)
+    wi, f, pdf = _sample_f(_mat(_abi.TK_MIRROR), 0, wo, nrm, [[0.3, 0.3]])
+    assert np.allclose(wi[0], [-0.6, 0, 0.8], atol=1e-6) and pdf[0] == 1
+    assert np.allclose(f[0], np.array([0.5, 0.6, 0.7]) / 0.8, rtol=1e-6)
+    # diffuse: cosine hemisphere about +N, f = R/pi, pdf = cos/pi
+    rng = np.random.default_rng(5)
+    u = rng.random((500, 2)).astype(np.float32)
+    wi, f, pdf = _sample_f(_mat(_abi.TK_DIFFUSE), 0, np.tile(wo, (500, 1)), np.tile(nrm, (500, 1)), u)
+    assert (wi[:, 2] >= 0).all() and np.allclose(np.linalg.norm(wi, axis=1), 1, atol=1e-5)
+    assert np.allclose(pdf, wi[:, 2] / math.pi, rtol=1e-5, atol=1e-7)
+    assert np.allclose(f, np.array([0.5, 0.6, 0.7]) / math.pi, rtol=1e-6)
+    assert abs(wi[:, 2].mean() - 2 / 3) < 0.03            # E[cos] of a cosine lobe
+    # from the back side the lobe is still about +N and the pdf collapses to 0 (src/core/Material.cpp:22-34)
+    wi, f, pdf = _sample_f(_mat(_abi.TK_DIFFUSE), 0, [[0.6, 0, -0.8]], nrm, [[0.4, 0.7]])
+    assert pdf[0] == 0 and (f[0] == 0).all()
+    # glass at normal incidence: Fresnel ((n-1)/(n+1))^2; u.x below it reflects, above it refracts straight through
+    g = _mat(_abi.TK_GLASS, 1.5)
+    fr = ((1.5 - 1) / (1.5 + 1)) ** 2
+    wi, f, pdf = _sample_f(g, 1, [[0, 0, 1]], nrm, [[fr * 0.5, 0.0]])
+    assert np.allclose(wi[0], [0, 0, 1]) and pdf[0] == pytest.approx(fr, rel=1e-5)
+    wi, f, pdf = _sample_f(g, 1, [[0, 0, 1]], nrm, [[0.9, 0.0]])
+    assert np.allclose(wi[0], [0, 0, -1]) and pdf[0] == pytest.approx(1 - fr, rel=1e-5)
+    assert np.allclose(f[0], (1 - fr) / 1.0, rtol=1e-5)                   # importance mode: no eta^2 factor
+    wi, f, pdf = _sample_f(g, 0, [[0, 0, 1]], nrm, [[0.9, 0.0]])
+    assert np.allclose(f[0], (1 - fr) / 1.5 ** 2, rtol=1e-5)              # radiance mode: (eta_i/eta_t)^2
+    # total internal reflection from inside: Fresnel 1, always reflects
+    s = math.sin(math.radians(60)); c = math.cos(math.radians(60))
+    wi, f, pdf = _sample_f(g, 0, [[s, 0, -c]], nrm, [[0.999, 0.0]])
+    assert pdf[0] == 1 and np.allclose(wi[0], [-s, 0, -c], atol=1e-6)
+
+
+def test_light_emission_sampling(sphere_scene):
+    osc = O.OracleScene(sphere_scene, 64, 64)
+    rng = np.random.default_rng(9)
+    n = 4000
+    u1 = rng.random((n, 2)).astype(np.float32); u2 = rng.random((n, 2)).astype(np.float32)
+    up = rng.random(n).astype(np.float32)
+    org = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32); nrm = np.empty((n, 3), np.float32)
+    le = np.empty((n, 3), np.float32); pp = np.empty(n, np.float32); pd = np.empty(n, np.float32)
+    L.orc_sample_le(osc.h, 0, n, O.fp(u1), O.fp(u2), O.fp(up), O.fp(org), O.fp(d), O.fp(nrm), O.fp(le), O.fp(pp), O.fp(pd))
+    # the Cornell light: y = 548.7*0.008 - 2.2, x in [213,343]*0.008-2.2, z in [227,332]*0.008, facing down
+    assert np.allclose(nrm, [0, -1, 0], atol=1e-6)
+    assert np.allclose(org[:, 1], 548.7 * 0.008 - 2.2, atol=1e-4)
+    assert org[:, 0].min() >= 213 * 0.008 - 2.2 - 1e-4 and org[:, 0].max() <= 343 * 0.008 - 2.2 + 1e-4
+    assert org[:, 2].min() >= 227 * 0.008 - 1e-4 and org[:, 2].max() <= 332 * 0.008 + 1e-4
+    area = (130 * 0.008) * (105 * 0.008)
+    assert np.allclose(pp, 1 / area, rtol=1e-3)            # P(triangle)/area(triangle) = 1/area(light)
+    assert (d[:, 1] <= 0).all() and np.allclose(pd, -d[:, 1] / math.pi, rtol=1e-4, atol=1e-6)
+    assert np.allclose(le[d[:, 1] < 0], [47.8348, 38.5664, 31.0808])
+    osc.close()
+
+
+# ---------------------------------------------------------------- whole passes
+def test_photon_pass_is_deterministic_and_fills_quota(sphere_scene):
+    osc = O.OracleScene(sphere_scene, 32, 32)
+    prm = sphere_scene.sppm_param(globalSize=3000, causticSize=400, numRecurse=2)
+    runs = []
+    for threads in (1, 4):
+        r = O.OracleSppm(osc, prm, 20, 0.8, 0x5EED, threads=threads)
+        st = r.photon_pass(0)
+        runs.append((st.global_paths, st.caustic_paths, *[a.copy() for a in r.photons(0, 3000)[:2]]))
+        assert st.global_stored == 3000 and st.caustic_stored == 400
+        assert 2.0 < 3000 / st.global_paths < 4.0           # about 2.4-3 photons stored per path
+        assert 0.02 < 400 / st.caustic_paths < 0.08         # caustic yield of the sphere scene about 4 %
+        r.close()
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert (runs[0][2] == runs[1][2]).all() and (runs[0][3] == runs[1][3]).all()
+    osc.close()
+
+
+def test_iterations_shrink_radius_and_accumulate(sphere_scene):
+    osc = O.OracleScene(sphere_scene, 48, 48)
+    prm = sphere_scene.sppm_param(globalSize=4000, causticSize=600, numRecurse=4)
+    r = O.OracleSppm(osc, prm, 20, 0.8, 7, threads=4)
+    prev = None
+    for it in range(3):
+        r.iteration(it)
+        px = r.pixels()
+        touched = px[:, 10] > 0
+        assert touched.any()
+        assert (px[touched, 12] <= np.float32(0.08)).all()
+        if prev is not None:
+            both = touched & (prev[:, 10] > 0)
+            assert (px[both, 12] <= prev[both, 12] * (1 + 1e-6)).all()      # radius never grows
+            assert (px[both, 10] >= prev[both, 10]).all()                   # photon count never drops
+        prev = px
+    img = r.resolve()
+    assert img.shape == (48, 48, 3) and img.mean() > 5
+    sg, sc_, nr = r.counters()
+    assert nr == 4 and sg > 0 and sc_ > 0
+    r.close()
+    osc.close()

@@ -1,0 +1,414 @@
+"""GPU parity tests: every stage of the HIP path against the CPU oracle on the
+same seeded inputs and against the committed golden vectors, all through the
+C ABI (libtkhip.so).  Bars: bit-exact for indices, counts, radii and ray hits;
+1e-5 relative for fp32 flux sums (summation order differs: stated in each test).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from pathtracer_amd import _abi
+from pathtracer_amd.scene import Scene, asset_scene
+from pathtracer_amd.tracer import Context, PhotonMap, SppmTracer
+from tests.conftest import golden, make_photons, make_queries
+
+pytestmark = pytest.mark.gpu
+L = O.lib()
+FLUX_RTOL = 1e-5
+
+
+def _flux_close(a, b):
+    scale = np.maximum(np.abs(b).max(axis=1, keepdims=True), 1e-20)
+    assert (np.abs(a - b) <= FLUX_RTOL * scale + 1e-12).all(), np.abs((a - b) / scale).max()
+
+
+# ------------------------------------------------------------------ scalar pieces
+def test_radical_inverse_matches_golden_and_oracle(gpu_ctx):
+    g = golden("radical_inverse.npz")
+    assert (gpu_ctx.radical_inverse(g["dim"], g["index"]) == g["value"]).all()
+    rng = np.random.default_rng(2)
+    dim = rng.integers(0, 7, 20000).astype(np.int32)
+    idx = rng.integers(0, 1 << 34, 20000).astype(np.uint64)
+    o = np.array([L.orc_radical_inverse(int(d), int(i)) for d, i in zip(dim, idx)], np.float32)
+    assert (gpu_ctx.radical_inverse(dim, idx) == o).all()
+
+
+def test_pixel_update_bit_exact(gpu_ctx):
+    g = golden("pixel_update.npz")
+    f, p, r = gpu_ctx.pixel_update(g["flux"], g["photons"], g["radius2"], g["lindir"], g["found"], g["r2ret"])
+    assert (f == g["flux_out"]).all() and (p == g["photons_out"]).all() and (r == g["radius2_out"]).all()
+
+
+# ------------------------------------------------------------------ rays
+@pytest.mark.parametrize("name", ["cornell_sphere", "cornell_box"])
+def test_ray_hits_match_golden(gpu_ctx, name):
+    sc = Scene.load(asset_scene(name + ".scene"))
+    g = golden(f"rays_{name}.npz")
+    gpu_ctx.set_scene(sc)
+    gpu_ctx.set_camera(sc, 512, 512)
+    org, d = gpu_ctx.camera_rays(g["raster"])
+    assert (org == g["org"]).all() and (d == g["dir"]).all()
+    for o_, d_, keys in ((g["org"], g["dir"], ("prim", "t", "p", "nrm", "perr")),
+                         (g["org2"], g["dir2"], ("prim2", "t2", "p2", "nrm2", "perr2"))):
+        out = gpu_ctx.trace_rays(o_, d_)
+        for got, key in zip(out, keys):
+            assert (got == g[key]).all(), key
+
+
+def test_ray_hits_match_oracle_on_the_dragon(gpu_ctx, dragon_scene):
+    """100k triangles: primary rays, incoherent secondary rays and shadow-style rays with a t_max."""
+    gpu_ctx.set_scene(dragon_scene)
+    gpu_ctx.set_camera(dragon_scene, 1024, 1024)
+    osc = O.OracleScene(dragon_scene, 1024, 1024)
+    rng = np.random.default_rng(4)
+    raster = np.stack([rng.random(60000) * 500 + 262, rng.random(60000) * 560 + 400], 1).astype(np.float32)  # around the dragon
+    org, d = gpu_ctx.camera_rays(raster)
+    oo, od = osc.camera_rays(raster)
+    assert (org == oo).all() and (d == od).all()
+    gp = gpu_ctx.trace_rays(org, d)
+    op = osc.trace(org, d)
+    for a, b in zip(gp, op):
+        assert (a == b).all()
+    hit = op[0] >= 0
+    assert hit.mean() > 0.9 and (op[0][hit] >= 12).mean() > 0.3          # a good share of the hits is on the dragon
+    m = int(hit.sum())
+    d2 = rng.normal(size=(m, 3)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    o2 = (op[2][hit] + 1e-3 * op[3][hit] * np.sign((d2 * op[3][hit]).sum(1, keepdims=True))).astype(np.float32)
+    tmax = np.where(rng.random(m) < 0.5, 0.5, 3.0e38).astype(np.float32)
+    gp2 = gpu_ctx.trace_rays(o2, d2, tmax)
+    op2 = osc.trace(o2, d2, tmax)
+    for a, b in zip(gp2, op2):
+        assert (a == b).all()
+    # the reference's traversal order (far child first, no culling) finds the same hits
+    of = osc.trace(o2[:3000], d2[:3000], tmax[:3000], faithful=1)
+    assert (of[0] == op2[0][:3000]).all() and (of[1] == op2[1][:3000]).all()
+    osc.close()
+
+
+# ------------------------------------------------------------------ kNN gather
+def _gpu_map(ctx, g_or_arrays, k):
+    pos, power, th, ph = g_or_arrays
+    m = PhotonMap(ctx, len(pos), k)
+    m.store(pos, power, th, ph)
+    m.build()
+    return m
+
+
+@pytest.mark.parametrize("name", ["knn_surface.npz", "knn_small_k50.npz", "knn_ties.npz"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_knn_matches_golden(gpu_ctx, name, mode):
+    g = golden(name)
+    m = _gpu_map(gpu_ctx, (g["pos"], g["power"], g["theta"], g["phi"]), int(g["k"]))
+    flux, found, r2o, idx = m.gather(g["qp"], g["qn"], g["qwo"], g["qR"], g["r2"], mode=mode)
+    assert (found == g["found"]).all()
+    assert (idx == g["idx"]).all()            # neighbour index sets, ties broken by photon index
+    assert (r2o == g["r2out"]).all()
+    _flux_close(flux, g["flux"])
+    m.close()
+
+
+@pytest.mark.parametrize("n,k,nq", [(50000, 100, 20000), (9000, 50, 8000), (700, 448, 500), (37, 100, 300), (1, 5, 50)])
+def test_knn_matches_oracle_random(gpu_ctx, n, k, nq):
+    rng = np.random.default_rng(n + k)
+    pos, power, th, ph = make_photons(rng, n)
+    qp, qn, qwo, qR, r2 = make_queries(rng, nq, radius2=(0.08, 0.5, 1e-3, 30.0))
+    gm = _gpu_map(gpu_ctx, (pos, power, th, ph), k)
+    nl, cap, depth, perm = gm.tree_info(n)
+    assert sorted(perm.tolist()) == list(range(n)) and nl * cap >= n and nl == 1 << depth
+    om = O.OracleMap(n, k)
+    om.store(pos, power, th, ph)
+    om.build(1)
+    of, ofound, or2, oidx = om.gather(qp, qn, qwo, qR, r2)
+    for mode in (0, 1):
+        gf, gfound, gr2, gidx = gm.gather(qp, qn, qwo, qR, r2, mode=mode)
+        assert (gfound == ofound).all() and (gidx == oidx).all() and (gr2 == or2).all()
+        _flux_close(gf, of)
+    gm.close()
+    om.close()
+
+
+def test_knn_edge_cases(gpu_ctx):
+    rng = np.random.default_rng(8)
+    qp, qn, qwo, qR, r2 = make_queries(rng, 130)
+    # empty map: nothing found, radius unchanged
+    m = PhotonMap(gpu_ctx, 16, 10)
+    m.build()
+    flux, found, r2o, idx = m.gather(qp, qn, qwo, qR, r2)
+    assert (found == 0).all() and (flux == 0).all() and (r2o == r2).all() and (idx == -1).all()
+    # zero and negative radii find nothing; gather before build is refused
+    pos, power, th, ph = make_photons(rng, 500)
+    m.close()
+    m = PhotonMap(gpu_ctx, 500, 10)
+    m.store(pos, power, th, ph)
+    with pytest.raises(_abi.TkError):
+        m.gather(qp, qn, qwo, qR, r2)
+    m.build()
+    r0 = np.zeros_like(r2)
+    r0[::2] = -1
+    flux, found, r2o, idx = m.gather(qp, qn, qwo, qR, r0)
+    assert (found == 0).all() and (r2o == r0).all()
+    # capacity and k limits
+    with pytest.raises(_abi.TkError):
+        m.store(pos, power, th, ph)
+    with pytest.raises(_abi.TkError):
+        PhotonMap(gpu_ctx, 10, _abi.TKHIP_MAX_K + 1)
+    m.close()
+
+
+def test_knn_full_size_properties(gpu_ctx):
+    """200k photons, 1M queries (the benchmark's map size): size-independent properties + a brute-force sample."""
+    rng = np.random.default_rng(77)
+    n, k, nq = 200000, 100, 1 << 20
+    pos, power, th, ph = make_photons(rng, n)
+    qp, qn, qwo, qR, r2 = make_queries(rng, nq, radius2=(0.02, 0.08, 0.002))
+    gm = _gpu_map(gpu_ctx, (pos, power, th, ph), k)
+    flux, found, r2o, idx = gm.gather(qp, qn, qwo, qR, r2, mode=0)
+    assert found.min() >= 0 and found.max() <= k
+    assert ((found < k) == (r2o == r2)).all() and (r2o <= r2).all()
+    assert ((idx >= 0).sum(axis=1) == found).all()
+    assert (flux >= 0).all() and np.isfinite(flux).all()
+    # mode 1 (per-query kernel only) agrees on a slice
+    f1, n1, r1, i1 = gm.gather(qp[:50000], qn[:50000], qwo[:50000], qR[:50000], r2[:50000], mode=1)
+    assert (n1 == found[:50000]).all() and (i1 == idx[:50000]).all() and (r1 == r2o[:50000]).all()
+    _flux_close(f1, flux[:50000])
+    # brute force on a sample
+    for q in rng.integers(0, nq, 40):
+        dv = pos - qp[q]
+        d2 = (dv[:, 0] * dv[:, 0] + dv[:, 1] * dv[:, 1]) + dv[:, 2] * dv[:, 2]
+        cand = np.nonzero(d2 < r2[q])[0]
+        order = cand[np.lexsort((cand, d2[cand]))][:k]
+        assert sorted(order.tolist()) == idx[q][idx[q] >= 0].tolist()
+    gm.close()
+
+
+# ------------------------------------------------------------------ whole passes
+def _tracers(scene, W, gs, cs, iters, seed=0x5EED):
+    tr = SppmTracer.from_scene(scene, globalSize=gs, causticSize=cs, numRecurse=iters, device=0, seed=seed)
+    tr.setScene(scene)
+    tr.setCamera(W, W)
+    tr.startRaytracing()
+    osc = O.OracleScene(scene, W, W)
+    orr = O.OracleSppm(osc, scene.sppm_param(globalSize=gs, causticSize=cs, numRecurse=iters), scene.tracer.max_depth,
+                       scene.tracer.russian_roulette, seed, threads=8, split_mode=1, faithful_bvh=0)
+    return tr, osc, orr
+
+
+@pytest.mark.parametrize("name,cs", [("cornell_sphere.scene", 3000), ("cornell_box.scene", 0)])
+def test_photon_pass_matches_oracle(name, cs):
+    """Same Halton indices, same hashed random numbers: the path counts are equal and the photon arrays agree
+    except where a transcendental differs in its last bit (cos/sin of the disk mapping) and flips a decision."""
+    scene = Scene.load(asset_scene(name))
+    tr, osc, orr = _tracers(scene, 64, 20000, cs, 4)
+    st = _abi.TkIterStats()
+    tr.photon_pass(0, st)
+    ost = orr.photon_pass(0)
+    assert st.global_stored == 20000 and st.caustic_stored == cs
+    assert abs(st.global_paths - ost.global_paths) <= 3
+    if cs:
+        assert abs(st.caustic_paths - ost.caustic_paths) <= max(30, ost.caustic_paths // 500)
+    for which, cap in ((0, 20000), (1, cs)):
+        if cap == 0:
+            continue
+        gpos, gpow, gth, gph = tr.photons(which)
+        opos, opow, oth, oph, _ = orr.photons(which, cap)
+        assert len(gpos) == len(opos) == cap
+        # align by position through a nearest-neighbour match of the two sets (order can shift after a divergence)
+        key_g = {tuple(np.round(p, 4)): i for i, p in enumerate(gpos)}
+        match = [(key_g.get(tuple(np.round(p, 4)), -1), j) for j, p in enumerate(opos)]
+        pairs = np.array([(i, j) for i, j in match if i >= 0])
+        assert len(pairs) > 0.97 * cap
+        gi, oj = pairs[:, 0], pairs[:, 1]
+        assert np.abs(gpos[gi] - opos[oj]).max() < 2e-4
+        rel = np.abs(gpow[gi] - opow[oj]) / np.maximum(np.abs(opow[oj]), 1e-6)
+        assert np.median(rel) < 1e-5 and (rel < 1e-3).mean() > 0.99
+        assert (np.abs(gth[gi].astype(int) - oth[oj].astype(int)) <= 1).mean() > 0.99
+    tr.close(); orr.close(); osc.close()
+
+
+def test_iterations_match_oracle_sphere_scene():
+    """Three full iterations (caustic + global maps): per-pixel SPPM state and the resolved image."""
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    W = 96
+    tr, osc, orr = _tracers(scene, W, 20000, 4000, 4)
+    for it in range(3):
+        st = tr.iteration()
+        ost = orr.iteration(it)
+        assert st.global_stored == ost.global_stored and st.caustic_stored == ost.caustic_stored
+        assert abs(st.shoot_global - ost.shoot_global) <= 6 * (it + 1)
+        assert abs(st.gathers_global - ost.gathers_global) <= 0.01 * ost.gathers_global
+        assert abs(st.gathers_caustic - ost.gathers_caustic) <= 0.01 * ost.gathers_caustic
+        assert abs(st.gather_photons - ost.gather_photons) <= 0.01 * ost.gather_photons
+    gpx, opx = tr.pixels(), orr.pixels()
+    # Ld (direct + emitted): identical sampling, fp32 agreement on nearly every pixel
+    close = np.abs(gpx[:, :3] - opx[:, :3]) <= 1e-4 * np.maximum(np.abs(opx[:, :3]), 1e-3)
+    assert close.mean() > 0.995
+    for lo, hi in ((3, 6), (6, 9), (9, 10), (10, 11), (11, 12), (12, 13)):
+        a, b = gpx[:, lo:hi], opx[:, lo:hi]
+        ok = np.abs(a - b) <= 1e-3 * np.maximum(np.abs(b), 1e-6)
+        assert ok.mean() > 0.97, (lo, ok.mean())          # the rest sit next to a photon whose path diverged
+        assert abs(a.mean() - b.mean()) <= 5e-3 * abs(b.mean())
+    gi, oi = tr.resolve().astype(np.float32), orr.resolve().astype(np.float32)
+    rmse = float(np.sqrt(((gi - oi) ** 2).mean()))
+    assert rmse < 1.5, rmse                               # RMSE on the 0..255 scale at matched iterations and seeds
+    assert (np.abs(gi - oi) <= 1).mean() > 0.97
+    sg, sc_, nr = tr.counters()
+    osg, osc_, onr = orr.counters()
+    assert nr == onr == 4 and abs(sg - osg) <= 20 and abs(sc_ - osc_) <= 0.01 * osc_
+    tr.close(); orr.close(); osc.close()
+
+
+def test_gather_on_identical_maps_and_hitpoints():
+    """The GPU's own photon maps and the oracle's camera hitpoints: with identical inputs the gather and the
+    SPPMPixel update agree to the last bit in counts / radii and to 1e-5 in flux."""
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    W = 64
+    tr, osc, orr = _tracers(scene, W, 15000, 3000, 4)
+    tr.iteration()
+    ctx = tr.ctx
+    for which, k in ((0, 100), (1, 50)):
+        pos, power, th, ph = tr.photons(which)
+        orr.set_map_photons(which, pos, power, th, ph, 1)
+        gm = PhotonMap(ctx, len(pos), k)
+        gm.store(pos, power, th, ph)
+        gm.build()
+        om = O.OracleMap(len(pos), k)
+        om.store(pos, power, th, ph)
+        om.build(0)                                       # reference tree shape (z-only splits)
+        qs = []
+        for y in range(0, W, 2):
+            for x in range(0, W, 2):
+                _, q = orr.camera_path(1, x, y)
+                qs += [e for e in q if e.which == which]
+        assert len(qs) > 200
+        qp = np.array([list(q.p) for q in qs], np.float32); qn = np.array([list(q.n) for q in qs], np.float32)
+        qwo = np.array([list(q.wo) for q in qs], np.float32); qR = np.array([list(q.R) for q in qs], np.float32)
+        r2 = np.full(len(qs), 0.03, np.float32)
+        of, ofound, or2, oidx = om.gather(qp, qn, qwo, qR, r2)
+        gf, gfound, gr2, gidx = gm.gather(qp, qn, qwo, qR, r2)
+        assert (gfound == ofound).all() and (gidx == oidx).all() and (gr2 == or2).all()
+        _flux_close(gf, of)
+        # the update rule on top of it
+        coef = np.array([list(q.coef) for q in qs], np.float32)
+        f0 = np.zeros((len(qs), 3), np.float32); p0 = np.zeros(len(qs), np.float32)
+        out = gpu_update = ctx.pixel_update(f0, p0, r2, coef * of, ofound, or2)
+        f1, p1, rr1 = f0.copy(), p0.copy(), r2.copy()
+        L.orc_pixel_update(len(qs), O.fp(f1), O.fp(p1), O.fp(rr1), O.fp(np.ascontiguousarray(coef * of)), O.ip(ofound), O.fp(or2))
+        assert (out[0] == f1).all() and (out[1] == p1).all() and (out[2] == rr1).all()
+        gm.close(); om.close()
+    tr.close(); orr.close(); osc.close()
+
+
+def test_resolve_matches_oracle():
+    scene = Scene.load(asset_scene("cornell_box.scene"))
+    tr, osc, orr = _tracers(scene, 48, 5000, 0, 4)
+    for _ in range(2):
+        tr.iteration()
+    px = tr.pixels()
+    sg, sc_, nr = tr.counters()
+    buf = (_abi.TkSPPMPixel * len(px)).from_buffer_copy(np.ascontiguousarray(px).tobytes())
+    oimg = np.zeros((48, 48, 3), np.uint8)
+    L.orc_resolve_rgb8(buf, 48, 48, nr, sg, sc_, 0, O.bp(oimg))
+    gimg = tr.resolve()
+    assert np.abs(gimg.astype(int) - oimg.astype(int)).max() <= 1      # powf may differ in its last bit
+    assert (gimg == oimg).mean() > 0.99
+    tr.close(); orr.close(); osc.close()
+
+
+def test_dragon_iteration_statistics(dragon_scene):
+    """The benchmark scene at reduced size: counts and image level against the oracle."""
+    W = 128
+    tr, osc, orr = _tracers(dragon_scene, W, 20000, 3000, 4)
+    for it in range(2):
+        st = tr.iteration()
+        ost = orr.iteration(it)
+        assert abs(st.global_paths - ost.global_paths) <= 0.01 * ost.global_paths
+        assert abs(st.caustic_paths - ost.caustic_paths) <= 0.03 * ost.caustic_paths
+        assert abs(st.gathers_global - ost.gathers_global) <= 0.01 * ost.gathers_global
+    gi, oi = tr.resolve().astype(np.float32), orr.resolve().astype(np.float32)
+    assert abs(gi.mean() - oi.mean()) < 0.5
+    assert float(np.sqrt(((gi - oi) ** 2).mean())) < 6.0
+    tr.close(); orr.close(); osc.close()
+
+
+def test_two_rank_sharding_on_one_gpu():
+    """rank 0 and rank 1 of a world of 2 as two contexts on this GPU, exchange by hand: the merged pixel state
+    equals the oracle's for the same sharding up to the usual divergent paths."""
+    import torch
+    from pathtracer_amd import distributed as D
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    W, GS, CS = 64, 8000, 1000
+    prm = scene.sppm_param(globalSize=GS, causticSize=CS, numRecurse=4)
+    bes = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, 2, 0) for r in range(2)]
+    osc = O.OracleScene(scene, W, W)
+    ors = [O.OracleSppm(osc, prm, 20, 0.8, 0x5EED, rank=r, world=2, threads=4) for r in range(2)]
+    for it in range(2):
+        for be, orc in zip(bes, ors):
+            be.photon_pass(it)
+            orc.photon_pass(it)
+        for which, size in ((0, GS), (1, CS)):
+            parts = [be.export_local(which) for be in bes]
+            assert [p[3] for p in parts] == [D.quota(size, r, 2) for r in range(2)]
+            cat = [torch.cat([p[i][:p[3]] for p in parts]).contiguous() for i in range(3)]
+            shot = sum(p[4] for p in parts)
+            for be in bes:
+                be.set_map(which, cat[0], cat[1], cat[2], size, shot)
+            op = [o.photons(which, size) for o in ors]
+            oshot = sum(p[4] for p in op)
+            assert abs(shot - oshot) <= max(4, 0.01 * oshot)
+            for o in ors:
+                o.set_map_photons(which, np.concatenate([p[0] for p in op]), np.concatenate([p[1] for p in op]),
+                                  np.concatenate([p[2] for p in op]), np.concatenate([p[3] for p in op]), oshot)
+        for be, orc in zip(bes, ors):
+            be.build_maps(); be.camera_pass(it)
+            orc.build_maps(); orc.camera_pass(it)
+    planes = [be.export_planes().cpu().numpy() for be in bes]
+    oplanes = [o.pixels().T.reshape(13, W, W) for o in ors]
+    owner = np.array([D.row_owner(y, 2) for y in range(W)])
+    for r in range(2):
+        mine, other = owner == r, owner != r
+        assert (planes[r][:11, other] == 0).all() and (planes[r][11:, other] == np.float32(0.08)).all()
+        a, b = planes[r][:, mine], oplanes[r][:, mine]
+        ok = np.abs(a - b) <= 1e-3 * np.maximum(np.abs(b), 1e-6)
+        assert ok.mean() > 0.95
+    # import / export round trip and resolve on the merged state
+    merged = planes[0].copy()
+    merged[:, owner == 1] = planes[1][:, owner == 1]
+    bes[0].import_planes(torch.from_numpy(merged).cuda())
+    assert np.array_equal(bes[0].export_planes().cpu().numpy(), merged)
+    img = bes[0].resolve()
+    assert img.shape == (W, W, 3) and img.mean() > 10
+    for be in bes:
+        be.close()
+    for o in ors:
+        o.close()
+    osc.close()
+
+
+def test_cpp_host_cli_renders_the_same_image(tmp_path):
+    """The C++ host program (loader + SppmTracer class over the C ABI) against the Python-driven render."""
+    scene_text = open(asset_scene("cornell_sphere.scene")).read()
+    scene_text = scene_text.replace('<gsize i="200000"/>', '<gsize i="6000"/>').replace('<csize i="50000"/>', '<csize i="800"/>')
+    scene_text = scene_text.replace('<recurse i="16"/>', '<recurse i="4"/>').replace("../models/", os.path.join(os.path.dirname(asset_scene("x")), "../models/"))
+    sf = tmp_path / "small.scene"
+    sf.write_text(scene_text)
+    out = tmp_path / "cli.ppm"
+    exe = os.path.join(_abi.LIB_DIR, "raytracer")
+    res = subprocess.run([exe, str(sf), "--width", "80", "--height", "80", "--out", str(out)], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert "Render complete" in res.stdout and "Rendering Done" in res.stderr
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n80 80\n255\n")
+    cli = np.frombuffer(data[len(b"P6\n80 80\n255\n"):], np.uint8).reshape(80, 80, 3)
+    sc = Scene.load(str(sf))
+    tr = SppmTracer.from_scene(sc, device=0)
+    tr.setScene(sc)
+    tr.setCamera(80, 80)
+    img = tr.render()
+    assert np.array_equal(cli, img)
+    tr.close()
