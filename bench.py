@@ -123,7 +123,8 @@ def main():
         acc = d if acc is None else {k: acc[k] + d[k] for k in d}
     sync()
     vals = torch.tensor([acc["rays"], acc["gathers_global"], acc["gathers_caustic"], acc["gather_photons"],
-                         acc["overflow_global"], acc["overflow_caustic"], acc["global_paths"], acc["caustic_paths"]],
+                         acc["overflow_global"], acc["overflow_caustic"], acc["global_paths"], acc["caustic_paths"],
+                         acc["group_staged"]],
                         dtype=torch.float64, device=dev)
     times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"]],
                          dtype=torch.float64, device=dev)
@@ -132,7 +133,7 @@ def main():
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     vals = (vals / n_inst).tolist()
     times = (times / n_inst).tolist()
-    rays, ng, nc, phot, og, oc, gpaths, cpaths = vals
+    rays, ng, nc, phot, og, oc, gpaths, cpaths, staged = vals
     ms_group, ms_photon, ms_build, ms_camera, ms_gather = times
 
     if rank == 0:
@@ -163,7 +164,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches_per_step": 2, "avg_launch_ms": ms_group / 2.0,
                          "algorithmic_bytes_per_step": bytes_group,
-                         "gathers_finished": done, "gathers_to_selection_kernel": og + oc},
+                         "gathers_finished": done, "gathers_to_selection_kernel": og + oc,
+                         "distance_tests_per_gather": staged * 64.0 / max(ng + nc, 1.0)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, param, max_depth, rr, seed, args.cpu_threads)

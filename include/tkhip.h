@@ -122,6 +122,8 @@ typedef struct TkIterStats {
     int64_t gather_photons;   /* sum of photons found over all gathers              */
     int64_t overflow_global;  /* global gathers that met >= k photons and went to   */
     int64_t overflow_caustic; /*   the per-query selection kernel (same, caustic)   */
+    int64_t group_staged;     /* photons the grouped gather kernel staged, summed   */
+                              /*   over its waves (x 64 lanes = distance tests)     */
     float ms_photon;          /* photon passes + compaction                         */
     float ms_build;           /* both KD-tree builds                                */
     float ms_camera;          /* camera paths incl. NEE, without gathers            */

@@ -59,6 +59,7 @@ class TkIterStats(C.Structure):
                 ("shoot_global", C.c_int64), ("shoot_caustic", C.c_int64),
                 ("rays", C.c_int64), ("gathers_global", C.c_int64), ("gathers_caustic", C.c_int64),
                 ("gather_photons", C.c_int64), ("overflow_global", C.c_int64), ("overflow_caustic", C.c_int64),
+                ("group_staged", C.c_int64),
                 ("ms_photon", C.c_float), ("ms_build", C.c_float), ("ms_camera", C.c_float),
                 ("ms_gather", C.c_float), ("ms_gather_kernel", C.c_float), ("ms_total", C.c_float)]
 

@@ -25,6 +25,7 @@ struct GatherOut {
     int64_t n_pixels;
     int32_t which;      // 0 global, 1 caustic: selects the planes to update
     unsigned long long* photon_sum;   // optional: sum of found over queries
+    unsigned long long* cand_sum;     // optional: photons staged by the grouped kernel, summed over waves (x64 = tests)
 };
 
 struct MapView {
@@ -39,6 +40,8 @@ struct MapView {
 
 struct tkhip_map {
     tkhip_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;   // where this map's copies, build and gathers are enqueued
+    tkd::DevBuf prim_temp;          // sort scratch of that stream
     int64_t cap = 0, n = 0;
     int k = 0;
     bool built = false;

@@ -319,14 +319,20 @@ TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay
     return wave_max_u64(kmax);
 }
 
+// Appends the photons of leaf node `node` that lie inside the current bound to
+// the candidate buffer.  Lanes [lane0, lane0+32) of the wave serve this leaf.
+static_assert(kLeafCap <= 32, "two leaves are served by the two halves of a wave");
+
 template <int EPL>
 __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, const int32_t* list,
                                                      const int32_t* list_count, int64_t nq, GatherOut out) {
     constexpr int CAP = 64 * EPL;
+    constexpr int FCAP = 256;            // frontier entries of the level-by-level descent
     __shared__ unsigned long long s_keys[4][CAP];
     __shared__ uint32_t s_pay[4][CAP];
     __shared__ int s_node[4][64];
     __shared__ float s_nd2[4][64];
+    __shared__ int s_front[4][2][FCAP];
     __shared__ float s_tab[1024];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
     __syncthreads();
@@ -337,6 +343,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
     float* st_d2 = s_nd2[wave];
     const int64_t total = list ? (int64_t)*list_count : nq;
     const int k = mv.k;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long found_sum = 0;
     for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < total; w += (int64_t)gridDim.x * 4) {
         const int64_t q = list ? (int64_t)list[w] : w;
@@ -344,45 +351,103 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         unsigned long long bound = (unsigned long long)__float_as_uint(Q.r2) << 32;
         float bound_d2 = Q.r2;
         int count = 0;
-        bool valid_r = Q.r2 > 0.f;
-        int sp = 0;
-        if (mv.n > 0 && valid_r) { st_node[0] = 1; st_d2[0] = 0.f; sp = 1; }
-        while (sp > 0) {
-            --sp;
-            const int node = uniform_i(st_node[sp]);
-            const float nd2 = uniform_f(st_d2[sp]);
-            if (!(nd2 < bound_d2)) continue;
-            if (node < mv.nl) {
-                const int c0 = 2 * node, c1 = c0 + 1;
-                const float d0 = box_dist2(mv, c0, Q.p), d1 = box_dist2(mv, c1, Q.p);
-                const bool near0 = d0 <= d1;
-                const int nn = near0 ? c0 : c1, fn = near0 ? c1 : c0;
-                const float dn = near0 ? d0 : d1, df = near0 ? d1 : d0;
-                if (df < bound_d2) { if (lane == 0) { st_node[sp] = fn; st_d2[sp] = df; } ++sp; }
-                if (dn < bound_d2) { if (lane == 0) { st_node[sp] = nn; st_d2[sp] = dn; } ++sp; }
-            } else {
+        const bool searchable = mv.n > 0 && Q.r2 > 0.f;
+
+        // The photons of one or two leaves against the bound; survivors join the buffer.
+        auto take_leaves = [&](int node_a, int node_b) {
+            const int half = lane >> 5, ph = lane & 31;
+            const int node = half ? node_b : node_a;
+            bool acc = false;
+            unsigned long long key = 0;
+            uint32_t at = 0;
+            if (node > 0) {
                 const int leaf = node - mv.nl;
-                const int64_t s = leaf_start(leaf, mv.n, mv.nl), e = leaf_start(leaf + 1, mv.n, mv.nl);
-                const int cnt = (int)(e - s);
-                bool acc = false;
-                unsigned long long key = 0;
-                if (lane < cnt) {
-                    float4 pp = mv.pos4[s + lane];
+                const int64_t s0 = leaf_start(leaf, mv.n, mv.nl), e0 = leaf_start(leaf + 1, mv.n, mv.nl);
+                if (ph < (int)(e0 - s0)) {
+                    at = (uint32_t)(s0 + ph);
+                    float4 pp = mv.pos4[at];
                     float d2 = dist2_exact(pp.x, pp.y, pp.z, Q.p);
                     key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(pp.w);
                     acc = key < bound;
                 }
-                unsigned long long m = __ballot(acc);
-                if (m) {
-                    int dst = count + __popcll(m & ((1ull << lane) - 1ull));
-                    if (acc) { keys[dst] = key; pay[dst] = (uint32_t)(s + lane); }
-                    count += __popcll(m);
-                    if (count > CAP - 64) {
-                        bound = wave_select_prune<EPL>(keys, pay, &count, k, lane);
-                        bound_d2 = __uint_as_float((uint32_t)(bound >> 32));
-                        // a photon exactly at the k-th distance can still win on its index
-                        bound_d2 = __uint_as_float(__float_as_uint(bound_d2) + 1u);
-                    }
+            }
+            unsigned long long m = __ballot(acc);
+            if (m) {
+                int dst = count + __popcll(m & lt_mask);
+                if (acc) { keys[dst] = key; pay[dst] = at; }
+                count += __popcll(m);
+                if (count > CAP - 64) {
+                    bound = wave_select_prune<EPL>(keys, pay, &count, k, lane);
+                    // a photon exactly at the k-th distance can still win on its index
+                    bound_d2 = __uint_as_float((uint32_t)(bound >> 32) + 1u);
+                }
+            }
+        };
+
+        // 1. Level-by-level descent: the lanes test the children of a whole frontier of nodes at
+        //    once, so a level costs one memory round trip instead of one per node.  The tree is
+        //    complete, every leaf sits at the same depth.
+        bool done = !searchable;
+        if (searchable) {
+            int (*front)[FCAP] = s_front[wave];
+            int cur = 0, fcount = 0;
+            const int l0 = mv.depth < 6 ? mv.depth : 6;
+            const int n0 = 1 << l0;
+            bool fits = true;
+            for (int base = 0; base < n0; base += 64) {
+                const int node = n0 + base + lane;
+                const bool keep = base + lane < n0 && box_dist2(mv, node, Q.p) < bound_d2;
+                unsigned long long m = __ballot(keep);
+                if (keep) front[cur][fcount + __popcll(m & lt_mask)] = node;
+                fcount += __popcll(m);
+            }
+            for (int level = l0; level < mv.depth && fits; ++level) {
+                int ncount = 0;
+                for (int e0 = 0; e0 < 2 * fcount; e0 += 64) {
+                    const int e = e0 + lane;
+                    const bool in = e < 2 * fcount;
+                    const int node = in ? 2 * front[cur][e >> 1] + (e & 1) : 0;
+                    const bool keep = in && box_dist2(mv, node, Q.p) < bound_d2;
+                    unsigned long long m = __ballot(keep);
+                    const int add = __popcll(m);
+                    if (ncount + add > FCAP) { fits = false; break; }
+                    if (keep) front[cur ^ 1][ncount + __popcll(m & lt_mask)] = node;
+                    ncount += add;
+                }
+                cur ^= 1;
+                fcount = ncount;
+            }
+            if (fits) {
+                for (int i = 0; i < fcount; i += 2) {
+                    const int na = front[cur][i], nb = i + 1 < fcount ? front[cur][i + 1] : 0;
+                    take_leaves(uniform_i(na), uniform_i(nb));
+                }
+                done = true;
+            }
+        }
+        // 2. A search region too wide for the frontier (huge radii): depth-first, near child first,
+        //    pruning against the bound as it tightens.
+        if (!done) {
+            count = 0;
+            bound = (unsigned long long)__float_as_uint(Q.r2) << 32;
+            bound_d2 = Q.r2;
+            int sp = 1;
+            if (lane == 0) { st_node[0] = 1; st_d2[0] = 0.f; }
+            while (sp > 0) {
+                --sp;
+                const int node = uniform_i(st_node[sp]);
+                const float nd2 = uniform_f(st_d2[sp]);
+                if (!(nd2 < bound_d2)) continue;
+                if (node < mv.nl) {
+                    const int c0 = 2 * node, c1 = c0 + 1;
+                    const float d0 = box_dist2(mv, c0, Q.p), d1 = box_dist2(mv, c1, Q.p);
+                    const bool near0 = d0 <= d1;
+                    const int nn = near0 ? c0 : c1, fn = near0 ? c1 : c0;
+                    const float dn = near0 ? d0 : d1, df = near0 ? d1 : d0;
+                    if (df < bound_d2) { if (lane == 0) { st_node[sp] = fn; st_d2[sp] = df; } ++sp; }
+                    if (dn < bound_d2) { if (lane == 0) { st_node[sp] = nn; st_d2[sp] = dn; } ++sp; }
+                } else {
+                    take_leaves(node, 0);
                 }
             }
         }
@@ -418,21 +483,36 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
 
 // ---------------------------------------- grouped kernel (64 queries per wave)
 // Queries arrive sorted along a Hilbert curve, so the 64 of a wave are
-// neighbours in space.  The wave walks the tree once with the union of their
-// search boxes; every photon of an overlapping leaf is broadcast from the lane
-// that loaded it and tested by all 64 queries at once.  A query that meets
-// fewer than k photons inside its radius is finished here (no selection is
-// needed: found < k keeps them all and leaves the radius unchanged); the rest
-// go to the per-query kernel.
+// neighbours in space.  The wave finds the leaves that overlap the union of
+// their search boxes by descending the tree level by level (the lanes test a
+// whole frontier of nodes at once: one memory round trip per level), then
+// streams those leaves through LDS two at a time: the lanes that loaded the
+// photons stage them, every lane reads them back as broadcasts and tests them
+// against its own query with a handful of branch-free vector instructions,
+// while the loads of the next two leaves are already in flight.
+// A query that meets fewer than k photons inside its radius is finished here
+// (no selection is needed: found < k keeps them all and leaves the radius
+// unchanged); the rest go to the per-query kernel.
+constexpr int kMaxGroupLeaves = 48;
+
+template <bool WANT_IDX>
 __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, const uint32_t* order, int64_t nq,
                                                       GatherOut out, int32_t* overflow, int32_t* overflow_count) {
+    constexpr int FCAP = 128;
     __shared__ float s_tab[1024];
+    __shared__ float4 s_pos[4][64];   // x, y, z, original index
+    __shared__ float4 s_dir[4][64];   // wi, power.r
+    __shared__ float2 s_pow[4][64];   // power.g, power.b
+    __shared__ int s_front[4][2][FCAP];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, ph = lane & 31;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int k = mv.k;
     const int64_t ngroups = (nq + 63) >> 6;
-    unsigned long long found_sum = 0;
+    int (*front)[FCAP] = s_front[wave];
+    unsigned long long found_sum = 0, staged_sum = 0;
     for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
         const int64_t slot = g * 64 + lane;
         const bool valid = slot < nq;
@@ -447,56 +527,93 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         const float hix = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.x + rr : -INFINITY));
         const float hiy = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.y + rr : -INFINITY));
         const float hiz = uniform_f(wave_max(Q.r2 > 0.f ? Q.p.z + rr : -INFINITY));
-        const float r2lo = Q.r2 * 0.999999f, r2hi = Q.r2 * 1.000001f;
         // a wave whose queries are spread out (ends of the curve, isolated surfaces) would test far
         // more photons than its queries need: it hands all of them to the per-query kernel instead
         const float own_sum = uniform_f(wave_sum(Q.r2 > 0.f ? 8.f * rr * rr * rr : 0.f));
         const int n_live = __popcll(__ballot(Q.r2 > 0.f));
-        const bool spread = n_live > 0 && (hix - lox) * (hiy - loy) * (hiz - loz) * (float)n_live > 64.f * own_sum;
+        bool spread = n_live > 0 && (hix - lox) * (hiy - loy) * (hiz - loz) * (float)n_live > 64.f * own_sum;
         int cnt = 0;
         float sx = 0, sy = 0, sz = 0;
+        auto overlaps = [&](int node) {
+            const float4 b0 = mv.node_box[2 * (int64_t)node], b1 = mv.node_box[2 * (int64_t)node + 1];
+            return b0.x <= hix && b0.w >= lox && b0.y <= hiy && b1.x >= loy && b0.z <= hiz && b1.y >= loz;
+        };
         if (mv.n > 0 && lox <= hix && !spread) {
-            // stackless depth-first walk of the implicit tree (heap numbering)
-            int node = 1;
-            do {
-                node = uniform_i(node);
-                const float4 b0 = mv.node_box[2 * (int64_t)node], b1 = mv.node_box[2 * (int64_t)node + 1];
-                const bool overlap = b0.x <= hix && b0.w >= lox && b0.y <= hiy && b1.x >= loy && b0.z <= hiz && b1.y >= loz;
-                if (overlap && node < mv.nl) { node = 2 * node; continue; }
-                if (overlap) {
-                    const int leaf = node - mv.nl;
-                    const int64_t s = leaf_start(leaf, mv.n, mv.nl), e = leaf_start(leaf + 1, mv.n, mv.nl);
-                    const int n_in = (int)(e - s);
-                    float px = 0, py = 0, pz = 0, pid = 0, wr = 0, wg = 0, wb = 0, wix = 0, wiy = 0, wiz = 0;
-                    if (lane < n_in) {
-                        float4 pp = mv.pos4[s + lane], pw = mv.pow4[s + lane];
-                        px = pp.x; py = pp.y; pz = pp.z; pid = pp.w;
-                        wr = pw.x; wg = pw.y; wb = pw.z;
+            // 1. leaves under the union box, level by level
+            int cur = 0, fcount = 0;
+            const int l0 = mv.depth < 6 ? mv.depth : 6;
+            const int n0 = 1 << l0;
+            {
+                const int node = n0 + lane;
+                const bool keep = lane < n0 && overlaps(node);
+                unsigned long long m = __ballot(keep);
+                if (keep) front[cur][__popcll(m & lt_mask)] = node;
+                fcount = __popcll(m);
+            }
+            for (int level = l0; level < mv.depth && !spread; ++level) {
+                int ncount = 0;
+                for (int e0 = 0; e0 < 2 * fcount; e0 += 64) {
+                    const int e = e0 + lane;
+                    const bool in = e < 2 * fcount;
+                    const int node = in ? 2 * front[cur][e >> 1] + (e & 1) : 0;
+                    const bool keep = in && overlaps(node);
+                    unsigned long long m = __ballot(keep);
+                    const int add = __popcll(m);
+                    if (ncount + add > FCAP) { spread = true; break; }
+                    if (keep) front[cur ^ 1][ncount + __popcll(m & lt_mask)] = node;
+                    ncount += add;
+                }
+                cur ^= 1;
+                fcount = ncount;
+            }
+            // A wave that would have to stream far more leaves than its neighbours (its queries straddle
+            // two surfaces, or one of them still has a large radius) would hold up the whole launch.
+            if (fcount > kMaxGroupLeaves) spread = true;
+            // 2. the photons of those leaves, two leaves per step, next step's loads in flight
+            if (!spread && fcount > 0) {
+                auto fetch = [&](int i, float4* pp, float4* pw, int* na, int* nb) {
+                    const int node_a = uniform_i(front[cur][i]);
+                    const int node_b = i + 1 < fcount ? uniform_i(front[cur][i + 1]) : 0;
+                    const int64_t sa = leaf_start(node_a - mv.nl, mv.n, mv.nl), ea = leaf_start(node_a - mv.nl + 1, mv.n, mv.nl);
+                    int64_t sb = 0, eb = 0;
+                    if (node_b) { sb = leaf_start(node_b - mv.nl, mv.n, mv.nl); eb = leaf_start(node_b - mv.nl + 1, mv.n, mv.nl); }
+                    *na = (int)(ea - sa);
+                    *nb = (int)(eb - sb);
+                    const int64_t at = half ? sb + ph : sa + ph;
+                    const bool has = ph < (half ? *nb : *na);
+                    if (has) { *pp = mv.pos4[at]; *pw = mv.pow4[at]; }
+                };
+                float4 pp = make_float4(0, 0, 0, 0), pw = pp;
+                int na = 0, nb = 0;
+                fetch(0, &pp, &pw, &na, &nb);
+                for (int i = 0; i < fcount; i += 2) {
+                    const int ca = na, cb = nb;
+                    __builtin_amdgcn_wave_barrier();      // the previous step has been read by every lane
+                    if (ph < (half ? cb : ca)) {
+                        const int at = half ? ca + ph : ph;
                         F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
-                        wix = wi.x; wiy = wi.y; wiz = wi.z;
+                        s_pos[wave][at] = pp;
+                        s_dir[wave][at] = make_float4(wi.x, wi.y, wi.z, pw.x);
+                        s_pow[wave][at] = make_float2(pw.y, pw.z);
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i + 2 < fcount) fetch(i + 2, &pp, &pw, &na, &nb);
+                    const int n_in = ca + cb;
+                    staged_sum += (unsigned long long)n_in;
+#pragma unroll 4
                     for (int c = 0; c < n_in; ++c) {
-                        const float cx = lane_f(px, c), cy = lane_f(py, c), cz = lane_f(pz, c);
-                        const float dx = cx - Q.p.x, dy = cy - Q.p.y, dz = cz - Q.p.z;
-                        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                        bool acc = d2f < r2hi;
-                        if (__any(acc)) {
-                            if (acc && !(d2f < r2lo)) acc = (dx * dx + dy * dy + dz * dz) < Q.r2;   // borderline: exact rule
-                            const float ax = lane_f(wix, c), ay = lane_f(wiy, c), az = lane_f(wiz, c);
-                            const float cs = ax * Q.n.x + ay * Q.n.y + az * Q.n.z;
-                            if (acc) {
-                                if (out.idx && cnt < k) out.idx[q * k + cnt] = __float_as_int(lane_f(pid, c));
-                                ++cnt;
-                                if (Q.won * cs > 0) {
-                                    const float ac = fabsf(cs);
-                                    sx += lane_f(wr, c) * ac; sy += lane_f(wg, c) * ac; sz += lane_f(wb, c) * ac;
-                                }
-                            }
-                        }
+                        const float4 P = s_pos[wave][c], D = s_dir[wave][c];   // LDS broadcasts
+                        const float2 Wp = s_pow[wave][c];
+                        const float dx = P.x - Q.p.x, dy = P.y - Q.p.y, dz = P.z - Q.p.z;
+                        const bool acc = (dx * dx + dy * dy + dz * dz) < Q.r2;      // the exact rule, strict
+                        const float cs = D.x * Q.n.x + D.y * Q.n.y + D.z * Q.n.z;
+                        const float wgt = (acc && Q.won * cs > 0) ? fabsf(cs) : 0.f;
+                        if (WANT_IDX) { if (acc && cnt < k) out.idx[q * k + cnt] = __float_as_int(P.w); }
+                        cnt += acc ? 1 : 0;
+                        sx = fmaf(D.w, wgt, sx); sy = fmaf(Wp.x, wgt, sy); sz = fmaf(Wp.y, wgt, sz);
                     }
                 }
-                node = (node + 1) >> __builtin_ctz((unsigned)(node + 1));
-            } while (node != 1);
+            }
         }
         const bool over = valid && (cnt >= k || (spread && Q.r2 > 0.f));
         if (valid && !over) finish_query(out, q, Q, cnt, Q.r2 > 0.f ? Q.r2 : qv.q0[q].w, mk3(sx, sy, sz));
@@ -506,6 +623,7 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         found_sum += (unsigned long long)fs;
     }
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
+    if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
 }
 
 // Position of a query along a 3-D Hilbert curve through the photon bounds
@@ -555,6 +673,7 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
     TK_REQUIRE(k >= 1 && k <= TKHIP_MAX_K, TKHIP_E_LIMIT, "map_create: sample count %d outside 1..%d", k, TKHIP_MAX_K);
     tkhip_map* m = new tkhip_map();
     m->ctx = ctx;
+    m->stream = ctx->stream;
     m->cap = capacity;
     m->k = k;
     size_t c = (size_t)(capacity > 0 ? capacity : 1);
@@ -572,7 +691,7 @@ void map_destroy(tkhip_map* m) {
     if (!m) return;
     DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->node_axis,
                       &m->clip_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
-                      &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters};
+                      &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters, &m->prim_temp};
     for (DevBuf* b : bufs) b->release();
     delete m;
 }
@@ -580,7 +699,7 @@ void map_destroy(tkhip_map* m) {
 int map_set_photons_device(tkhip_map* m, const float* pos, const float* power, const uint16_t* dir, int64_t n) {
     TK_REQUIRE(n >= 0 && n <= m->cap, TKHIP_E_LIMIT, "map_set_photons: %lld photons exceed capacity %lld", (long long)n,
                (long long)m->cap);
-    hipStream_t s = m->ctx->stream;
+    hipStream_t s = m->stream;
     if (n > 0) {
         TK_HIP(hipMemcpyAsync(m->in_pos.p, pos, (size_t)n * 12, hipMemcpyDeviceToDevice, s));
         TK_HIP(hipMemcpyAsync(m->in_pow.p, power, (size_t)n * 12, hipMemcpyDeviceToDevice, s));
@@ -592,8 +711,7 @@ int map_set_photons_device(tkhip_map* m, const float* pos, const float* power, c
 }
 
 int map_build(tkhip_map* m) {
-    tkhip_ctx* ctx = m->ctx;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = m->stream;
     const int64_t n = m->n;
     m->built = false;
     if (n == 0) { m->nl = 0; m->depth = 0; m->built = true; return TKHIP_OK; }
@@ -629,7 +747,7 @@ int map_build(tkhip_map* m) {
             k_level_keys<<<divup(n, B), B, 0, s>>>(pos, idx, m->node_axis.as<int32_t>(), m->key_a.as<uint64_t>(), n, nl,
                                                    depth, level);
             TK_LAUNCH_CHECK();
-            TK_TRY(sort_pairs_u64(ctx, m->key_a.as<uint64_t>(), m->key_b.as<uint64_t>(), idx, idx_alt, (size_t)n,
+            TK_TRY(sort_pairs_u64(s, m->prim_temp, m->key_a.as<uint64_t>(), m->key_b.as<uint64_t>(), idx, idx_alt, (size_t)n,
                                   32 + level));
             std::swap(idx, idx_alt);
             k_level_split<<<divup(nodes, B), B, 0, s>>>(pos, idx, m->clip_box.as<float>(), m->node_axis.as<int32_t>(), n,
@@ -675,15 +793,14 @@ template <int EPL>
 static void launch_wave(tkhip_map* m, const QueryView& qv, const int32_t* list, const int32_t* list_count,
                         int64_t nq, int64_t work_hint, const GatherOut& out) {
     int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(work_hint, 4), 1), 256 * 16);
-    k_gather_wave<EPL><<<blocks, 256, 0, m->ctx->stream>>>(m->view(), qv, list, list_count, nq, out);
+    k_gather_wave<EPL><<<blocks, 256, 0, m->stream>>>(m->view(), qv, list, list_count, nq, out);
 }
 
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed) {
     TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
     if (nq == 0) return TKHIP_OK;
     TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
-    tkhip_ctx* ctx = m->ctx;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = m->stream;
     const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
     auto wave_all = [&](const int32_t* list, const int32_t* cnt, int64_t hint) {
         if (epl == 2) launch_wave<2>(m, qv, list, cnt, nq, hint, out);
@@ -709,7 +826,7 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     F3 binv{ex > 0 ? 1023.f / ex : 0.f, ey > 0 ? 1023.f / ey : 0.f, ez > 0 ? 1023.f / ez : 0.f};
     k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, bmin, binv, m->q_keys_a.as<uint32_t>(), m->q_vals_a.as<uint32_t>());
     TK_LAUNCH_CHECK();
-    TK_TRY(sort_pairs_u32(ctx, m->q_keys_a.as<uint32_t>(), m->q_keys_b.as<uint32_t>(), m->q_vals_a.as<uint32_t>(),
+    TK_TRY(sort_pairs_u32(s, m->prim_temp, m->q_keys_a.as<uint32_t>(), m->q_keys_b.as<uint32_t>(), m->q_vals_a.as<uint32_t>(),
                           m->q_order.as<uint32_t>(), (size_t)nq, 30));
     int32_t* ocount = m->counters.as<int32_t>();
     TK_HIP(hipMemsetAsync(ocount, 0, 4, s));
@@ -721,8 +838,12 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     }
     const int64_t groups = (nq + 63) / 64;
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), 256 * 32);
-    k_gather_group<<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out, m->overflow.as<int32_t>(),
-                                          ocount);
+    if (out.idx)
+        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
+                                                    m->overflow.as<int32_t>(), ocount);
+    else
+        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
+                                                     m->overflow.as<int32_t>(), ocount);
     TK_LAUNCH_CHECK();
     if (timed) {
         TK_HIP(hipEventRecord(e1, s));
@@ -785,7 +906,7 @@ int tkhip_map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
 void tkhip_map_destroy(tkhip_map* map) {
     if (!map) return;
     (void)hipSetDevice(map->ctx->device);
-    (void)hipStreamSynchronize(map->ctx->stream);
+    (void)hipStreamSynchronize(map->stream);
     map_destroy(map);
 }
 
@@ -797,7 +918,7 @@ int tkhip_map_store(tkhip_map* m, const float* pos, const float* power, const ui
     if (n == 0) return TKHIP_OK;
     tkhip_ctx* ctx = m->ctx;
     TK_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = m->stream;
     TK_TRY(ctx->scratch_a.ensure((size_t)n * 12));
     TK_TRY(ctx->scratch_b.ensure((size_t)n * 12));
     TK_TRY(ctx->scratch_c.ensure((size_t)n * 2));
@@ -820,7 +941,7 @@ int tkhip_map_build(tkhip_map* m) {
     TK_REQUIRE(m, TKHIP_E_ARG, "tkhip_map_build: null map");
     TK_HIP(hipSetDevice(m->ctx->device));
     TK_TRY(map_build(m));
-    TK_HIP(hipStreamSynchronize(m->ctx->stream));
+    TK_HIP(hipStreamSynchronize(m->stream));
     return TKHIP_OK;
 }
 
@@ -844,7 +965,7 @@ int tkhip_map_gather(tkhip_map* m, int64_t nq, const float* p, const float* n, c
     if (nq == 0) return TKHIP_OK;
     tkhip_ctx* ctx = m->ctx;
     TK_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = m->stream;
     const size_t q = (size_t)nq;
     DevBuf in, qb, ob;
     int rc = in.ensure(q * 52);

@@ -16,6 +16,10 @@
 // photons in path order and the shoot counter is the index of the path that
 // filled it, which is what a single CPU thread produces.
 #include <algorithm>
+#include <chrono>
+#include <future>
+#include <string>
+#include <thread>
 
 #include "photon_map.h"
 #include "tk_bvh_device.h"
@@ -24,7 +28,33 @@ namespace tkd {
 
 constexpr int kTailThreshold = 1 << 18;   // live paths at or below which a pass switches to its tail kernel
 
-enum { C_QA = 0, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */ };
+enum { C_QA = 0, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */ };
+
+// Everything one concurrently running pass needs: its stream, path state,
+// queues, counters and scratch.  Lane 0 traces the global photons and builds
+// the global map, lane 1 does the same for the caustic map, lane 2 traces the
+// camera paths.  The three run side by side in tkhip_sppm_iteration: all of
+// them are bound by the latency of single rays, not by throughput.
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf st_o, st_d, st_w, queue_a, queue_b, counters;
+    DevBuf stage_pos, stage_pow, rec_count, rec_offset, prim_temp;
+    int ensure_paths(int64_t n) {
+        TK_TRY(st_o.ensure((size_t)n * 16));
+        TK_TRY(st_d.ensure((size_t)n * 16));
+        TK_TRY(st_w.ensure((size_t)n * 16));
+        TK_TRY(queue_a.ensure((size_t)n * 4));
+        TK_TRY(queue_b.ensure((size_t)n * 4));
+        return TKHIP_OK;
+    }
+    void release() {
+        DevBuf* bufs[] = {&st_o, &st_d, &st_w, &queue_a, &queue_b, &counters, &stage_pos, &stage_pow, &rec_count,
+                          &rec_offset, &prim_temp};
+        for (DevBuf* b : bufs) b->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
 
 struct SppmState {
     TkSppmParam prm{};
@@ -43,11 +73,9 @@ struct SppmState {
     int64_t n_pixels = 0;
     int n_rows = 0;
     int64_t n_slots = 0;
-    // path state and queues
-    DevBuf st_o, st_d, st_w, queue_a, queue_b, counters;
-    DevBuf stage_pos, stage_pow, rec_count, rec_offset;
+    Lane lane[3];
     DevBuf qbuf[2];
-    int64_t path_cap = 0;
+    int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
 };
 
 struct PathState {
@@ -518,69 +546,62 @@ void destroy_sppm(tkhip_ctx* ctx) {
         if (s->map[w]) map_destroy(s->map[w]);
         s->loc_pos[w].release(); s->loc_pow[w].release(); s->loc_dir[w].release(); s->qbuf[w].release();
     }
-    DevBuf* bufs[] = {&s->planes, &s->rows, &s->st_o, &s->st_d, &s->st_w, &s->queue_a, &s->queue_b, &s->counters,
-                      &s->stage_pos, &s->stage_pow, &s->rec_count, &s->rec_offset};
-    for (DevBuf* b : bufs) b->release();
+    s->planes.release();
+    s->rows.release();
+    for (Lane& l : s->lane) l.release();
     delete s;
     ctx->sppm = nullptr;
 }
 
-static int ensure_paths(SppmState* s, int64_t n) {
-    TK_TRY(s->st_o.ensure((size_t)n * 16));
-    TK_TRY(s->st_d.ensure((size_t)n * 16));
-    TK_TRY(s->st_w.ensure((size_t)n * 16));
-    TK_TRY(s->queue_a.ensure((size_t)n * 4));
-    TK_TRY(s->queue_b.ensure((size_t)n * 4));
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int read_u64_counter(Lane& l, int at, int64_t* out) {
+    unsigned long long v = 0;
+    int32_t* c = l.counters.as<int32_t>();
+    TK_HIP(hipMemcpyAsync(&v, &c[at], 8, hipMemcpyDeviceToHost, l.stream));
+    TK_HIP(hipStreamSynchronize(l.stream));
+    TK_HIP(hipMemsetAsync(&c[at], 0, 8, l.stream));
+    *out = (int64_t)v;
     return TKHIP_OK;
 }
 
-struct Timer {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t s;
-    bool on;
-    Timer(hipStream_t st, bool enable) : s(st), on(enable) {
-        if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s); }
-    }
-    float stop() {
-        float ms = 0.f;
-        if (on) { (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); }
-        return ms;
-    }
-    ~Timer() { if (on) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } }
-};
-
+// The photon pass of one map on its lane.  Returns with the lane's stream idle.
 template <int KIND>
-static int photon_pass_kind(tkhip_ctx* ctx, TkIterStats* st) {
+static int photon_pass_kind(tkhip_ctx* ctx) {
     SppmState* s = ctx->sppm;
-    hipStream_t stream = ctx->stream;
+    Lane& ln = s->lane[KIND];
+    hipStream_t stream = ln.stream;
     const int64_t quota = s->quota[KIND];
     int64_t stored = 0, shot = 0;
     const int slots = KIND == 0 ? s->max_depth : 1;
     const int depth = KIND == 0 ? s->max_depth : 64;
-    int32_t* counters = s->counters.as<int32_t>();
+    int32_t* counters = ln.counters.as<int32_t>();
     const int64_t emitted_cap = KIND == 0 ? (int64_t)1 << 40 : quota * 4000 + 100000;
     int32_t host_counters[16];
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
     while (stored < quota && shot < emitted_cap) {
         int64_t need = quota - stored;
         int64_t B = (int64_t)((double)need / s->yield[KIND] * 1.02) + 256;
         B = std::min<int64_t>(B, (int64_t)1 << 24);
-        TK_TRY(ensure_paths(s, B));
-        TK_TRY(s->stage_pos.ensure((size_t)B * slots * 16));
-        TK_TRY(s->stage_pow.ensure((size_t)B * slots * 16));
-        TK_TRY(s->rec_count.ensure((size_t)B * 4));
-        TK_TRY(s->rec_offset.ensure((size_t)B * 4));
+        TK_TRY(ln.ensure_paths(B));
+        TK_TRY(ln.stage_pos.ensure((size_t)B * slots * 16));
+        TK_TRY(ln.stage_pow.ensure((size_t)B * slots * 16));
+        TK_TRY(ln.rec_count.ensure((size_t)B * 4));
+        TK_TRY(ln.rec_offset.ensure((size_t)B * 4));
         PhotonArgs a;
         a.sc = ctx->scene;
-        a.st = PathState{s->st_o.as<float4>(), s->st_d.as<float4>(), s->st_w.as<float4>()};
-        a.rec_count = s->rec_count.as<int32_t>();
-        a.stage_pos = s->stage_pos.as<float4>();
-        a.stage_pow = s->stage_pow.as<float4>();
+        a.st = PathState{ln.st_o.as<float4>(), ln.st_d.as<float4>(), ln.st_w.as<float4>()};
+        a.rec_count = ln.rec_count.as<int32_t>();
+        a.stage_pos = ln.stage_pos.as<float4>();
+        a.stage_pow = ln.stage_pow.as<float4>();
         a.m0 = s->local_shot[KIND] + shot;
-        a.hoff = KIND == 0 ? 0 : s->local_shot[0];
+        a.hoff = KIND == 0 ? 0 : s->local_shot[0];   // caustic index = j + shootGlobalPhotons (TkSppmTracer.cpp:419)
         a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
         TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
-        int32_t* qa = s->queue_a.as<int32_t>();
-        int32_t* qb = s->queue_b.as<int32_t>();
+        int32_t* qa = ln.queue_a.as<int32_t>();
+        int32_t* qb = ln.queue_b.as<int32_t>();
         const int grid = divup(B, 256);
         k_photon_emit<KIND><<<grid, 256, 0, stream>>>(a, B, qa, counters);
         TK_LAUNCH_CHECK();
@@ -608,9 +629,9 @@ static int photon_pass_kind(tkhip_ctx* ctx, TkIterStats* st) {
                 live_bound = live;
             }
         }
-        TK_TRY(exclusive_scan_i32(ctx, s->rec_count.as<int32_t>(), s->rec_offset.as<int32_t>(), (size_t)B));
-        k_photon_scatter<<<grid, 256, 0, stream>>>(s->rec_count.as<int32_t>(), s->rec_offset.as<int32_t>(),
-                                                   s->stage_pos.as<float4>(), s->stage_pow.as<float4>(), slots, B, stored,
+        TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
+        k_photon_scatter<<<grid, 256, 0, stream>>>(ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(),
+                                                   ln.stage_pos.as<float4>(), ln.stage_pow.as<float4>(), slots, B, stored,
                                                    quota, s->loc_pos[KIND].as<float>(), s->loc_pow[KIND].as<float>(),
                                                    s->loc_dir[KIND].as<uint16_t>(), counters);
         TK_LAUNCH_CHECK();
@@ -628,18 +649,6 @@ static int photon_pass_kind(tkhip_ctx* ctx, TkIterStats* st) {
     s->n_loc[KIND] = stored;
     s->last_shot[KIND] = shot;
     s->local_shot[KIND] += shot;
-    (void)st;
-    return TKHIP_OK;
-}
-
-static int read_u64_counter(tkhip_ctx* ctx, int at, bool reset, int64_t* out) {
-    SppmState* s = ctx->sppm;
-    unsigned long long v = 0;
-    int32_t* c = s->counters.as<int32_t>();
-    TK_HIP(hipMemcpyAsync(&v, &c[at], 8, hipMemcpyDeviceToHost, ctx->stream));
-    TK_HIP(hipStreamSynchronize(ctx->stream));
-    if (reset) TK_HIP(hipMemsetAsync(&c[at], 0, 8, ctx->stream));
-    *out = (int64_t)v;
     return TKHIP_OK;
 }
 
@@ -650,6 +659,177 @@ static int install_map(tkhip_ctx* ctx, int which, const float* pos, const float*
     s->shoot[which] += shot_total;
     if (which == 1) s->stored_c = n;
     return TKHIP_OK;
+}
+static int install_local(tkhip_ctx* ctx, int which) {
+    SppmState* s = ctx->sppm;
+    return install_map(ctx, which, s->loc_pos[which].as<float>(), s->loc_pow[which].as<float>(),
+                       s->loc_dir[which].as<uint16_t>(), s->n_loc[which], s->last_shot[which]);
+}
+
+// Camera paths of this rank's pixels on lane 2: direct light into the pixel
+// planes, gather queries into the two query buffers.  The photon maps are not
+// read here, so this runs beside the photon passes.  expect_caustic: emit
+// caustic queries (they are dropped later if the caustic map stays empty).
+static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
+    SppmState* s = ctx->sppm;
+    Lane& ln = s->lane[2];
+    hipStream_t stream = ln.stream;
+    int32_t* counters = ln.counters.as<int32_t>();
+    s->n_queries[0] = s->n_queries[1] = 0;
+    if (s->n_slots == 0) return TKHIP_OK;
+    CameraArgs a;
+    a.sc = ctx->scene; a.cam = ctx->cam;
+    a.st = PathState{ln.st_o.as<float4>(), ln.st_d.as<float4>(), ln.st_w.as<float4>()};
+    a.rows = s->rows.as<int32_t>();
+    a.planes = s->planes.as<float>();
+    a.n_pixels = s->n_pixels;
+    a.iter = iter; a.spp = s->num_recurse; a.xs = s->xs; a.ys = s->ys; a.depth = s->max_depth;
+    a.seed = s->seed;
+    a.caustic_stored = expect_caustic ? 1 : 0;
+    a.gq = s->qbuf[0].as<float4>();
+    a.cq = s->qbuf[1].as<float4>();
+    a.qcap = s->n_slots;
+    TK_HIP(hipMemsetAsync(counters, 0, 4 * 4, stream));
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
+    int32_t* qa = ln.queue_a.as<int32_t>();
+    int32_t* qb = ln.queue_b.as<int32_t>();
+    k_camera_gen<<<divup(s->n_slots, 256), 256, 0, stream>>>(a, s->n_slots, qa);
+    int32_t nslots32 = (int32_t)s->n_slots;
+    TK_HIP(hipMemcpyAsync(&counters[C_QA], &nslots32, 4, hipMemcpyHostToDevice, stream));
+    TK_LAUNCH_CHECK();
+    int64_t live_bound = s->n_slots;
+    int ca = C_QA, cb = C_QB;
+    for (int b = 0; b < s->max_depth; ++b) {
+        TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
+        k_camera_bounce<<<divup(live_bound, 256), 256, 0, stream>>>(a, b, qa, &counters[ca], qb, counters, cb);
+        TK_LAUNCH_CHECK();
+        std::swap(qa, qb);
+        std::swap(ca, cb);
+        if (b + 1 < s->max_depth && (b == 1 || b == 3 || b == 7 || b == 15 || b == 31)) {
+            int32_t live = 0;
+            TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
+            TK_HIP(hipStreamSynchronize(stream));
+            if (live == 0) break;
+            if (live <= kTailThreshold) {
+                k_camera_tail<<<divup(live, kTailBlock), kTailBlock, 0, stream>>>(a, b + 1, qa, &counters[ca], counters);
+                TK_LAUNCH_CHECK();
+                break;
+            }
+            live_bound = live;
+        }
+    }
+    int32_t hc[4];
+    TK_HIP(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, stream));
+    TK_HIP(hipStreamSynchronize(stream));
+    s->n_queries[0] = hc[C_NGQ];
+    s->n_queries[1] = hc[C_NCQ];
+    return TKHIP_OK;
+}
+
+// radiance_estimate + SPPMPixel update for the queries of one map, on that
+// map's stream (the two maps update disjoint planes and can run side by side).
+static int camera_gather(tkhip_ctx* ctx, int which, bool timed) {
+    SppmState* s = ctx->sppm;
+    int64_t nq = s->n_queries[which];
+    if (which == 1 && s->stored_c == 0) nq = 0;   // src/tracer/TkSppmTracer.cpp:323
+    s->n_queries[which] = nq;
+    if (nq == 0) { s->map[which]->last_group_ms = 0.f; s->map[which]->last_overflow = 0; return TKHIP_OK; }
+    float4* q = s->qbuf[which].as<float4>();
+    QueryView qv{q, q + s->n_slots, q + 2 * s->n_slots, q + 3 * s->n_slots};
+    GatherOut out{};
+    out.planes = s->planes.as<float>();
+    out.n_pixels = s->n_pixels;
+    out.which = which;
+    out.photon_sum = reinterpret_cast<unsigned long long*>(&s->lane[which].counters.as<int32_t>()[C_PHOT]);
+    out.cand_sum = reinterpret_cast<unsigned long long*>(&s->lane[which].counters.as<int32_t>()[C_CAND]);
+    TK_HIP(hipMemsetAsync(out.photon_sum, 0, 16, s->map[which]->stream));
+    TK_TRY(map_gather_device(s->map[which], nq, qv, out, 0, timed));
+    TK_HIP(hipStreamSynchronize(s->map[which]->stream));
+    return TKHIP_OK;
+}
+
+// Runs fn on a worker thread bound to the context's device; its error text is
+// carried back to the caller's thread.
+struct Worker {
+    std::thread th;
+    int rc = TKHIP_OK;
+    std::string err;
+    template <class F>
+    void start(tkhip_ctx* ctx, F fn) {
+        th = std::thread([this, ctx, fn]() {
+            if (hipSetDevice(ctx->device) != hipSuccess) { rc = TKHIP_E_HIP; err = "hipSetDevice failed in worker"; return; }
+            rc = fn();
+            if (rc != TKHIP_OK) err = tkhip_last_error();
+        });
+    }
+    int join() {
+        if (th.joinable()) th.join();
+        if (rc != TKHIP_OK) set_error("%s", err.c_str());
+        return rc;
+    }
+};
+
+static int build_both(tkhip_ctx* ctx, double* ms) {
+    SppmState* s = ctx->sppm;
+    double t0 = now_ms();
+    Worker w;
+    const bool caustic = s->stored_c > 0;   // src/tracer/TkSppmTracer.cpp:477-478
+    if (caustic) w.start(ctx, [s]() { TK_TRY(map_build(s->map[1])); TK_HIP(hipStreamSynchronize(s->map[1]->stream)); return TKHIP_OK; });
+    int rc = map_build(s->map[0]);
+    if (rc == TKHIP_OK && hipStreamSynchronize(s->map[0]->stream) != hipSuccess) { set_error("build: stream sync failed"); rc = TKHIP_E_HIP; }
+    int rc1 = w.join();
+    if (ms) *ms += now_ms() - t0;
+    return rc != TKHIP_OK ? rc : rc1;
+}
+
+static int gather_both(tkhip_ctx* ctx, TkIterStats* st) {
+    SppmState* s = ctx->sppm;
+    double t0 = now_ms();
+    const bool timed = st != nullptr;
+    // Timed (instrumented) calls run the two gathers one after the other so that the event-timed
+    // duration of each grouped kernel is its own; otherwise they share the GPU.
+    Worker w;
+    int rc, rc1 = TKHIP_OK;
+    if (timed) {
+        rc = camera_gather(ctx, 1, true);
+        if (rc == TKHIP_OK) rc = camera_gather(ctx, 0, true);
+    } else {
+        w.start(ctx, [ctx]() { return camera_gather(ctx, 1, false); });
+        rc = camera_gather(ctx, 0, false);
+        rc1 = w.join();
+    }
+    if (rc != TKHIP_OK) return rc;
+    if (rc1 != TKHIP_OK) return rc1;
+    if (st) {
+        st->ms_gather += (float)(now_ms() - t0);
+        st->ms_gather_kernel += s->map[0]->last_group_ms + s->map[1]->last_group_ms;
+        st->overflow_global += s->map[0]->last_overflow;
+        st->overflow_caustic += s->map[1]->last_overflow;
+        st->gathers_global += s->n_queries[0];
+        st->gathers_caustic += s->n_queries[1];
+        for (int which = 0; which < 2; ++which) {
+            int64_t phot = 0, cand = 0;
+            TK_TRY(read_u64_counter(s->lane[which], C_PHOT, &phot));
+            TK_TRY(read_u64_counter(s->lane[which], C_CAND, &cand));
+            st->gather_photons += phot;
+            st->group_staged += cand;
+        }
+    }
+    return TKHIP_OK;
+}
+
+static int collect_rays(tkhip_ctx* ctx, int lane, TkIterStats* st) {
+    if (!st) return TKHIP_OK;
+    int64_t rays = 0;
+    TK_TRY(read_u64_counter(ctx->sppm->lane[lane], C_RAYS, &rays));
+    st->rays += rays;
+    return TKHIP_OK;
+}
+
+static void fill_photon_stats(SppmState* s, TkIterStats* st) {
+    st->global_paths = s->last_shot[0]; st->caustic_paths = s->last_shot[1];
+    st->global_stored = s->n_loc[0]; st->caustic_stored = s->n_loc[1];
+    st->shoot_global = s->shoot[0]; st->shoot_caustic = s->shoot[1];
 }
 
 }  // namespace tkd
@@ -680,9 +860,24 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     int x = 0, y = 0;
     while (++x * ++y < param->numRecurse) {}   // src/tracer/TkSppmTracer.cpp:18-21
     s->num_recurse = x * y; s->xs = x; s->ys = y;
-    int rc = map_create(ctx, param->globalSize, param->globalSample, &s->map[0]);
+    int rc = TKHIP_OK;
+    // One priority level per lane: streams of different priority never share a hardware queue,
+    // so the three lanes cannot end up serialised behind one another.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int prio[3] = {prio_greatest, (prio_least + prio_greatest) / 2, prio_least};
+    int lane_no = 0;
+    for (Lane& l : s->lane) {
+        if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio[lane_no++]) != hipSuccess) { set_error("tkhip_sppm_begin: hipStreamCreate failed"); rc = TKHIP_E_HIP; break; }
+        rc = l.counters.ensure(64);
+        if (rc) break;
+        if (hipMemsetAsync(l.counters.p, 0, 64, l.stream) != hipSuccess) { set_error("tkhip_sppm_begin: memset failed"); rc = TKHIP_E_HIP; break; }
+    }
+    if (!rc) rc = map_create(ctx, param->globalSize, param->globalSample, &s->map[0]);
     if (!rc) rc = map_create(ctx, std::max(param->causticSize, 1), param->causticSample, &s->map[1]);
     if (rc) { destroy_sppm(ctx); return rc; }
+    s->map[0]->stream = s->lane[0].stream;
+    s->map[1]->stream = s->lane[1].stream;
     s->quota[0] = param->globalSize / world + (rank < param->globalSize % world ? 1 : 0);
     s->quota[1] = param->causticSize / world + (rank < param->causticSize % world ? 1 : 0);
     for (int w = 0; w < 2 && !rc; ++w) {
@@ -700,15 +895,14 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     s->n_slots = (int64_t)s->n_rows * W;
     if (!rc) rc = s->planes.ensure((size_t)s->n_pixels * 13 * 4);
     if (!rc) rc = s->rows.ensure(std::max<size_t>(rows.size(), 1) * 4);
-    if (!rc) rc = s->counters.ensure(64);
-    if (!rc) rc = ensure_paths(s, std::max<int64_t>(s->n_slots, 1));
+    if (!rc) rc = s->lane[2].ensure_paths(std::max<int64_t>(s->n_slots, 1));
     for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
     if (rc) { destroy_sppm(ctx); return rc; }
     if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    TK_HIP(hipMemsetAsync(s->counters.p, 0, 64, ctx->stream));
     k_init_planes<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, param->radius2);
     TK_LAUNCH_CHECK();
     TK_HIP(hipStreamSynchronize(ctx->stream));
+    for (Lane& l : s->lane) TK_HIP(hipStreamSynchronize(l.stream));
     return TKHIP_OK;
 }
 
@@ -716,27 +910,22 @@ int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_photon_pass");
     (void)iter;
     SppmState* s = ctx->sppm;
-    Timer tm(ctx->stream, st != nullptr);
-    TK_HIP(hipMemsetAsync(&s->counters.as<int32_t>()[C_RAYS], 0, 8, ctx->stream));
-    TK_TRY(photon_pass_kind<0>(ctx, st));
-    if (s->quota[1] > 0) TK_TRY(photon_pass_kind<1>(ctx, st));
+    double t0 = now_ms();
+    TK_TRY(photon_pass_kind<0>(ctx));
+    if (s->quota[1] > 0) TK_TRY(photon_pass_kind<1>(ctx));
     else { s->n_loc[1] = 0; s->last_shot[1] = 0; }
     if (s->world == 1) {
-        TK_TRY(install_map(ctx, 0, s->loc_pos[0].as<float>(), s->loc_pow[0].as<float>(), s->loc_dir[0].as<uint16_t>(),
-                           s->n_loc[0], s->last_shot[0]));
-        TK_TRY(install_map(ctx, 1, s->loc_pos[1].as<float>(), s->loc_pow[1].as<float>(), s->loc_dir[1].as<uint16_t>(),
-                           s->n_loc[1], s->last_shot[1]));
+        TK_TRY(install_local(ctx, 0));
+        TK_TRY(install_local(ctx, 1));
+        TK_HIP(hipStreamSynchronize(s->lane[0].stream));
+        TK_HIP(hipStreamSynchronize(s->lane[1].stream));
     }
     if (st) {
-        int64_t rays = 0;
-        TK_TRY(read_u64_counter(ctx, C_RAYS, true, &rays));
-        st->ms_photon += tm.stop();
-        st->rays += rays;
-        st->global_paths = s->last_shot[0]; st->caustic_paths = s->last_shot[1];
-        st->global_stored = s->n_loc[0]; st->caustic_stored = s->n_loc[1];
-        st->shoot_global = s->shoot[0]; st->shoot_caustic = s->shoot[1];
+        TK_TRY(collect_rays(ctx, 0, st));
+        TK_TRY(collect_rays(ctx, 1, st));
+        st->ms_photon += (float)(now_ms() - t0);
+        fill_photon_stats(s, st);
     }
-    TK_HIP(hipStreamSynchronize(ctx->stream));
     return TKHIP_OK;
 }
 
@@ -766,18 +955,15 @@ int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, cons
     TK_REQUIRE(which == 0 || which == 1, TKHIP_E_ARG, "tkhip_sppm_set_map_photons: which must be 0 or 1");
     TK_REQUIRE(n == 0 || (pos && power && dir), TKHIP_E_ARG, "tkhip_sppm_set_map_photons: null buffer");
     TK_TRY(install_map(ctx, which, pos, power, dir, n, shot_total));
-    TK_HIP(hipStreamSynchronize(ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->sppm->map[which]->stream));
     return TKHIP_OK;
 }
 
 int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_build_maps");
-    SppmState* s = ctx->sppm;
-    Timer tm(ctx->stream, st != nullptr);
-    TK_TRY(map_build(s->map[0]));
-    if (s->stored_c > 0) TK_TRY(map_build(s->map[1]));   // src/tracer/TkSppmTracer.cpp:477-478
-    if (st) st->ms_build += tm.stop();
-    TK_HIP(hipStreamSynchronize(ctx->stream));
+    double ms = 0;
+    TK_TRY(build_both(ctx, &ms));
+    if (st) st->ms_build += (float)ms;
     return TKHIP_OK;
 }
 
@@ -785,101 +971,72 @@ int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_camera_pass");
     SppmState* s = ctx->sppm;
     TK_REQUIRE(s->map[0]->built, TKHIP_E_STATE, "tkhip_sppm_camera_pass: build the photon maps first");
-    hipStream_t stream = ctx->stream;
-    int32_t* counters = s->counters.as<int32_t>();
-    int64_t ng = 0, nc = 0;
-    if (s->n_slots > 0) {
-        Timer tcam(stream, st != nullptr);
-        CameraArgs a;
-        a.sc = ctx->scene; a.cam = ctx->cam;
-        a.st = PathState{s->st_o.as<float4>(), s->st_d.as<float4>(), s->st_w.as<float4>()};
-        a.rows = s->rows.as<int32_t>();
-        a.planes = s->planes.as<float>();
-        a.n_pixels = s->n_pixels;
-        a.iter = iter; a.spp = s->num_recurse; a.xs = s->xs; a.ys = s->ys; a.depth = s->max_depth;
-        a.seed = s->seed;
-        a.caustic_stored = (int)s->stored_c;
-        a.gq = s->qbuf[0].as<float4>();
-        a.cq = s->qbuf[1].as<float4>();
-        a.qcap = s->n_slots;
-        TK_HIP(hipMemsetAsync(counters, 0, 4 * 4, stream));
-        TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 16, stream));
-        int32_t* qa = s->queue_a.as<int32_t>();
-        int32_t* qb = s->queue_b.as<int32_t>();
-        k_camera_gen<<<divup(s->n_slots, 256), 256, 0, stream>>>(a, s->n_slots, qa);
-        int32_t nslots32 = (int32_t)s->n_slots;
-        TK_HIP(hipMemcpyAsync(&counters[C_QA], &nslots32, 4, hipMemcpyHostToDevice, stream));
-        TK_LAUNCH_CHECK();
-        int64_t live_bound = s->n_slots;
-        int ca = C_QA, cb = C_QB;
-        for (int b = 0; b < s->max_depth; ++b) {
-            TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
-            k_camera_bounce<<<divup(live_bound, 256), 256, 0, stream>>>(a, b, qa, &counters[ca], qb, counters, cb);
-            TK_LAUNCH_CHECK();
-            std::swap(qa, qb);
-            std::swap(ca, cb);
-            if (b + 1 < s->max_depth && (b == 1 || b == 3 || b == 7 || b == 15 || b == 31)) {
-                int32_t live = 0;
-                TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
-                TK_HIP(hipStreamSynchronize(stream));
-                if (live == 0) break;
-                if (live <= kTailThreshold) {
-                    k_camera_tail<<<divup(live, kTailBlock), kTailBlock, 0, stream>>>(a, b + 1, qa, &counters[ca], counters);
-                    TK_LAUNCH_CHECK();
-                    break;
-                }
-                live_bound = live;
-            }
-        }
-        int32_t hc[4];
-        TK_HIP(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, stream));
-        TK_HIP(hipStreamSynchronize(stream));
-        ng = hc[C_NGQ]; nc = hc[C_NCQ];
-        if (st) st->ms_camera += tcam.stop();
-        // gathers with the fused pixel update
-        Timer tg(stream, st != nullptr);
-        float group_ms = 0.f;
-        for (int which = 1; which >= 0; --which) {
-            int64_t nq = which == 0 ? ng : nc;
-            if (nq == 0) continue;
-            float4* q = s->qbuf[which].as<float4>();
-            QueryView qv{q, q + s->n_slots, q + 2 * s->n_slots, q + 3 * s->n_slots};
-            GatherOut out{};
-            out.planes = s->planes.as<float>();
-            out.n_pixels = s->n_pixels;
-            out.which = which;
-            out.photon_sum = reinterpret_cast<unsigned long long*>(&counters[C_PHOT]);
-            TK_TRY(map_gather_device(s->map[which], nq, qv, out, 0, st != nullptr));
-            group_ms += s->map[which]->last_group_ms;
-            if (st) (which == 0 ? st->overflow_global : st->overflow_caustic) += s->map[which]->last_overflow;
-        }
-        if (st) {
-            st->ms_gather += tg.stop();
-            st->ms_gather_kernel += group_ms;
-        }
-    }
-    if (st) {
-        int64_t rays = 0, phot = 0;
-        TK_TRY(read_u64_counter(ctx, C_RAYS, true, &rays));
-        TK_TRY(read_u64_counter(ctx, C_PHOT, true, &phot));
-        st->rays += rays;
-        st->gathers_global += ng; st->gathers_caustic += nc; st->gather_photons += phot;
-    }
-    TK_HIP(hipStreamSynchronize(stream));
+    double t0 = now_ms();
+    TK_TRY(camera_trace(ctx, iter, s->stored_c > 0));
+    if (st) st->ms_camera += (float)(now_ms() - t0);
+    TK_TRY(gather_both(ctx, st));
+    TK_TRY(collect_rays(ctx, 2, st));
     return TKHIP_OK;
 }
 
+// One iteration on a single GPU.  The camera paths do not read the photon
+// maps until they gather, so three things run side by side: the global photon
+// pass followed by the global tree build, the caustic photon pass (it starts
+// when the global pass has fixed its Halton offset) followed by the caustic
+// tree build, and the camera paths.  The gathers of both maps follow, again
+// side by side.  The per-phase times of the stats therefore overlap.
 int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_iteration");
-    TK_REQUIRE(ctx->sppm->world == 1, TKHIP_E_STATE,
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->world == 1, TKHIP_E_STATE,
                "tkhip_sppm_iteration: with world > 1 drive the passes and the photon exchange separately");
-    Timer tm(ctx->stream, st != nullptr);
-    TK_TRY(tkhip_sppm_photon_pass(ctx, iter, st));
-    TK_TRY(tkhip_sppm_build_maps(ctx, st));
-    TK_TRY(tkhip_sppm_camera_pass(ctx, iter, st));
+    const double t0 = now_ms();
+    double t_photon_end[2] = {t0, t0}, build_ms[2] = {0, 0};
+    std::promise<int> global_pass_done;
+    std::future<int> global_pass_rc = global_pass_done.get_future();
+    Worker wg, wc;
+    wg.start(ctx, [&, ctx, s]() {
+        int rc = photon_pass_kind<0>(ctx);
+        if (rc == TKHIP_OK) rc = install_local(ctx, 0);
+        t_photon_end[0] = now_ms();
+        global_pass_done.set_value(rc);
+        if (rc != TKHIP_OK) return rc;
+        double b0 = now_ms();
+        TK_TRY(map_build(s->map[0]));
+        TK_HIP(hipStreamSynchronize(s->map[0]->stream));
+        build_ms[0] = now_ms() - b0;
+        return TKHIP_OK;
+    });
+    wc.start(ctx, [&, ctx, s]() {
+        if (global_pass_rc.get() != TKHIP_OK) return TKHIP_OK;   // the global worker reports its own failure
+        if (s->quota[1] > 0) TK_TRY(photon_pass_kind<1>(ctx));
+        else { s->n_loc[1] = 0; s->last_shot[1] = 0; }
+        TK_TRY(install_local(ctx, 1));
+        TK_HIP(hipStreamSynchronize(s->map[1]->stream));
+        t_photon_end[1] = now_ms();
+        if (s->stored_c > 0) {   // src/tracer/TkSppmTracer.cpp:477-478
+            double b0 = now_ms();
+            TK_TRY(map_build(s->map[1]));
+            TK_HIP(hipStreamSynchronize(s->map[1]->stream));
+            build_ms[1] = now_ms() - b0;
+        }
+        return TKHIP_OK;
+    });
+    int rc_cam = camera_trace(ctx, iter, s->quota[1] > 0);
+    const double t_cam = now_ms();
+    int rc_g = wg.join();
+    int rc_c = wc.join();
+    if (rc_g != TKHIP_OK) return rc_g;
+    if (rc_c != TKHIP_OK) return rc_c;
+    if (rc_cam != TKHIP_OK) return rc_cam;
+    TK_TRY(gather_both(ctx, st));
     if (st) {
-        st->ms_total += tm.stop();
-        st->shoot_global = ctx->sppm->shoot[0]; st->shoot_caustic = ctx->sppm->shoot[1];
+        for (int l = 0; l < 3; ++l) TK_TRY(collect_rays(ctx, l, st));
+        st->ms_photon += (float)(std::max(t_photon_end[0], t_photon_end[1]) - t0);
+        st->ms_build += (float)(build_ms[0] + build_ms[1]);
+        st->ms_camera += (float)(t_cam - t0);
+        st->ms_total += (float)(now_ms() - t0);
+        fill_photon_stats(s, st);
     }
     return TKHIP_OK;
 }

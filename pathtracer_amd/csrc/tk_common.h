@@ -161,12 +161,13 @@ struct tkhip_ctx {
 
 namespace tkd {
 
-// rocPRIM wrappers (tk_prims.hip).  All asynchronous on ctx->stream.
-int sort_pairs_u64(tkhip_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout,
+// rocPRIM wrappers (tk_prims.hip).  Asynchronous on `stream`; `temp` is the
+// caller's scratch allocation (one per stream, grown on demand).
+int sort_pairs_u64(hipStream_t stream, DevBuf& temp, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout,
                    size_t n, int end_bit);
-int sort_pairs_u32(tkhip_ctx* ctx, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout,
+int sort_pairs_u32(hipStream_t stream, DevBuf& temp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout,
                    size_t n, int end_bit);
-int exclusive_scan_i32(tkhip_ctx* ctx, const int32_t* in, int32_t* out, size_t n);
+int exclusive_scan_i32(hipStream_t stream, DevBuf& temp, const int32_t* in, int32_t* out, size_t n);
 
 int upload_direction_tables(tkhip_ctx* ctx);
 void destroy_sppm(tkhip_ctx* ctx);

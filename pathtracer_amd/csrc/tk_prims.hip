@@ -9,31 +9,31 @@
 namespace tkd {
 
 template <class K>
-static int sort_pairs_impl(tkhip_ctx* ctx, K* kin, K* kout, uint32_t* vin, uint32_t* vout, size_t n, int end_bit) {
+static int sort_pairs_impl(hipStream_t stream, DevBuf& temp, K* kin, K* kout, uint32_t* vin, uint32_t* vout, size_t n, int end_bit) {
     if (n == 0) return TKHIP_OK;
     size_t bytes = 0;
-    TK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, end_bit, ctx->stream));
-    TK_TRY(ctx->prim_temp.ensure(bytes));
-    TK_HIP(rocprim::radix_sort_pairs(ctx->prim_temp.p, bytes, kin, kout, vin, vout, n, 0, end_bit, ctx->stream));
+    TK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, end_bit, stream));
+    TK_TRY(temp.ensure(bytes));
+    TK_HIP(rocprim::radix_sort_pairs(temp.p, bytes, kin, kout, vin, vout, n, 0, end_bit, stream));
     return TKHIP_OK;
 }
 
-int sort_pairs_u64(tkhip_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
+int sort_pairs_u64(hipStream_t stream, DevBuf& temp, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                    int end_bit) {
-    return sort_pairs_impl<uint64_t>(ctx, kin, kout, vin, vout, n, end_bit);
+    return sort_pairs_impl<uint64_t>(stream, temp, kin, kout, vin, vout, n, end_bit);
 }
 
-int sort_pairs_u32(tkhip_ctx* ctx, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
+int sort_pairs_u32(hipStream_t stream, DevBuf& temp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                    int end_bit) {
-    return sort_pairs_impl<uint32_t>(ctx, kin, kout, vin, vout, n, end_bit);
+    return sort_pairs_impl<uint32_t>(stream, temp, kin, kout, vin, vout, n, end_bit);
 }
 
-int exclusive_scan_i32(tkhip_ctx* ctx, const int32_t* in, int32_t* out, size_t n) {
+int exclusive_scan_i32(hipStream_t stream, DevBuf& temp, const int32_t* in, int32_t* out, size_t n) {
     if (n == 0) return TKHIP_OK;
     size_t bytes = 0;
-    TK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int32_t>(), ctx->stream));
-    TK_TRY(ctx->prim_temp.ensure(bytes));
-    TK_HIP(rocprim::exclusive_scan(ctx->prim_temp.p, bytes, in, out, 0, n, rocprim::plus<int32_t>(), ctx->stream));
+    TK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int32_t>(), stream));
+    TK_TRY(temp.ensure(bytes));
+    TK_HIP(rocprim::exclusive_scan(temp.p, bytes, in, out, 0, n, rocprim::plus<int32_t>(), stream));
     return TKHIP_OK;
 }
 

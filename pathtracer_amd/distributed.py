@@ -54,6 +54,12 @@ class HipBackend:
         self.max_quota = [quota(param.globalSize, 0, world), quota(param.causticSize, 0, world)]
         self.num_recurse = self.tracer.num_recurse
 
+    def iteration_single(self, it, stats=None):
+        """world == 1: the library overlaps the photon passes, the tree builds and the camera paths."""
+        lib = self.lib
+        check(lib, lib.tkhip_sppm_iteration(self.h, it, C.byref(stats) if stats is not None else None),
+              "tkhip_sppm_iteration")
+
     def photon_pass(self, it, stats=None):
         self.tracer.photon_pass(it, stats)
 
@@ -121,6 +127,9 @@ def exchange_photons(backend, which, world):
 
 def iteration(backend, it, world, stats=None):
     """photon pass -> exchange -> tree builds -> camera pass, for every rank in lockstep."""
+    if world == 1 and hasattr(backend, "iteration_single"):
+        backend.iteration_single(it, stats)
+        return [None, None]
     backend.photon_pass(it, stats)
     totals = [exchange_photons(backend, which, world) for which in (0, 1)]
     backend.build_maps(stats)
