@@ -29,33 +29,64 @@ WORKLOAD = "cornell_dragon.scene"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, GB/s
 
 
-def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
-    """The CPU oracle (a port of the reference algorithm) on a bounded sample of the same workload."""
-    from oracle import oracle_py as O
-    osc = O.OracleScene(scene, width, height)
-    # fair CPU mode: widest-axis KD-tree, near-first BVH with culling, hashed RNG
-    r = O.OracleSppm(osc, param, max_depth, rr, seed, threads=threads, split_mode=1, faithful_bvh=0, rng_cost=0)
+def _oracle_iteration(O, osc, param, max_depth, rr, seed, threads, height, budget_s, **mode):
+    """One oracle iteration, the camera pass sampled in 8-row bands spread evenly over the image
+    (bit-reversed band order) until budget_s seconds are spent; returns seconds per full iteration."""
+    r = O.OracleSppm(osc, param, max_depth, rr, seed, threads=threads, **mode)
     t0 = time.time()
     st_p = r.photon_pass(0)
     t1 = time.time()
     r.build_maps()
     t2 = time.time()
-    rows = max(8, height // 32)
-    y0 = height // 2 - rows // 2
-    st_c = r.camera_pass(0, y0, y0 + rows)
+    bands = list(range(0, height, 8))
+    bits = max(1, (len(bands) - 1).bit_length())
+    order = sorted(range(len(bands)), key=lambda i: int(format(i, f"0{bits}b")[::-1], 2))
+    rows = rays = gathers = 0
+    for i in order:
+        y0 = bands[i]
+        y1 = min(y0 + 8, height)
+        st = r.camera_pass(0, y0, y1)
+        rows += y1 - y0
+        rays += st.rays
+        gathers += st.gathers_global + st.gathers_caustic
+        if time.time() - t0 > budget_s and rows >= 32:
+            break
     t3 = time.time()
-    scale = height / rows
-    sec_iter = (t1 - t0) + (t2 - t1) + (t3 - t2) * scale
-    rays = st_p.rays + st_c.rays * scale
-    gathers = (st_c.gathers_global + st_c.gathers_caustic) * scale
     r.close()
+    scale = height / rows
+    sec = (t2 - t0) + (t3 - t2) * scale
+    return {"sec_iter": sec, "photon_s": t1 - t0, "build_s": t2 - t1, "camera_s": t3 - t2, "rows": rows,
+            "rays": st_p.rays + rays * scale, "gathers": gathers * scale, "spent_s": t3 - t0}
+
+
+def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
+    """The CPU oracle (a port of the reference algorithm) on a bounded sample of the same workload,
+    in its reference-faithful mode (the reported value) and in a fair mode beside it."""
+    from oracle import oracle_py as O
+    osc = O.OracleScene(scene, width, height)
+    # as the reference computes: z-only KD splits, far-first BVH without t_max culling, one Mersenne
+    # Twister construction per random number
+    ref = _oracle_iteration(O, osc, param, max_depth, rr, seed, threads, height, 12.0,
+                            split_mode=0, faithful_bvh=1, rng_cost=1)
+    # the same port with those three costs removed: widest-axis KD-tree, near-first culled BVH, hashed RNG
+    fair = _oracle_iteration(O, osc, param, max_depth, rr, seed, threads, height, 8.0,
+                             split_mode=1, faithful_bvh=0, rng_cost=0)
     osc.close()
+
+    def describe(m):
+        return (f"full photon pass {m['photon_s']:.2f}s + both KD builds {m['build_s']:.2f}s + camera pass on "
+                f"{m['rows']} of {height} rows in 8-row bands spread over the image {m['camera_s']:.2f}s "
+                f"(scaled x{height / m['rows']:.1f})")
     return {
-        "value": 1.0 / sec_iter, "unit": "iterations/s", "cores": threads, "kind": "port",
-        "sample": (f"CPU oracle, iteration 0: full photon pass ({t1 - t0:.2f}s) + both KD builds ({t2 - t1:.2f}s) + "
-                   f"camera pass on {rows} of {height} rows ({t3 - t2:.2f}s, scaled x{scale:.0f}); widest-axis KD-tree, "
-                   f"near-first culled BVH, hashed RNG (the reference's per-call Mersenne-Twister seeding is not charged)"),
-        "mrays_per_s": rays / sec_iter / 1e6, "gathers_per_s": gathers / sec_iter,
+        "value": 1.0 / ref["sec_iter"], "unit": "iterations/s", "cores": threads, "kind": "port",
+        "sample": ("CPU oracle, iteration 0 of the same workload, reference-faithful mode (z-only KD splits, far-first "
+                   "BVH without t_max culling, per-call Mersenne-Twister seeding): " + describe(ref)),
+        "mrays_per_s": ref["rays"] / ref["sec_iter"] / 1e6, "gathers_per_s": ref["gathers"] / ref["sec_iter"],
+        "fair_mode": {"value": 1.0 / fair["sec_iter"], "unit": "iterations/s",
+                      "sample": "widest-axis KD-tree, near-first culled BVH, hashed RNG: " + describe(fair),
+                      "mrays_per_s": fair["rays"] / fair["sec_iter"] / 1e6,
+                      "gathers_per_s": fair["gathers"] / fair["sec_iter"]},
+        "cpu_seconds_spent": ref["spent_s"] + fair["spent_s"],
     }
 
 
