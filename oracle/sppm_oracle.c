@@ -15,6 +15,9 @@
  *  - Photon paths are numbered like the worker threads number them
  *    (haltonIdx = ++shootGlobalPhotons, src/tracer/TkSppmTracer.cpp:414) and
  *    stored in path order; the reference interleaves threads under a mutex.
+ *    Caustic path j uses index j + (global paths shot in earlier iterations);
+ *    the reference adds the global count at the time of the call (:419), which
+ *    includes the current iteration and would chain the two passes.
  *  - Every tile of the image is traced (the reference skips the trailing
  *    tiles when width or height is not a multiple of 20,
  *    src/core/TkRayTracer.cpp:115-117).
@@ -1393,6 +1396,7 @@ struct orc_sppm {
     /* this rank's traced photons (before exchange) */
     PhotonRec* loc_g; int64_t n_loc_g; PhotonRec* loc_c; int64_t n_loc_c;
     int64_t local_shot_g, local_shot_c;     /* cumulative local path counters */
+    int64_t caustic_hoff;                   /* global paths shot before the current iteration */
     int64_t last_shot_g, last_shot_c;       /* paths of the last pass */
     int64_t shoot_g, shoot_c;               /* cumulative over all ranks */
     int64_t stored_c;
@@ -1511,8 +1515,10 @@ static void photon_pass_kind(orc_sppm* r, int kind, TkIterStats* st) {
     PhotonRec* out = kind == 0 ? r->loc_g : r->loc_c;
     int64_t stored = 0, shot = 0;
     int64_t m0 = kind == 0 ? r->local_shot_g : r->local_shot_c;
-    /* caustic Halton index = j + shootGlobalPhotons (src/tracer/TkSppmTracer.cpp:419) */
-    int64_t hoff = kind == 0 ? 0 : r->local_shot_g;
+    /* caustic Halton index = j + shootGlobalPhotons (src/tracer/TkSppmTracer.cpp:419), with the
+     * global count taken at the start of the iteration so that the two passes of an iteration
+     * do not depend on each other */
+    int64_t hoff = kind == 0 ? 0 : r->caustic_hoff;
     int slots = kind == 0 ? r->max_depth : 1;
     double* yield = kind == 0 ? &r->yield_g : &r->yield_c;
     TraceCounters tcs[256]; memset(tcs, 0, sizeof(tcs));
@@ -1548,6 +1554,7 @@ static void install_map(orc_map* m, const PhotonRec* recs, int64_t n) {
 
 void orc_sppm_photon_pass(orc_sppm* r, int iter, TkIterStats* st) {
     (void)iter;
+    r->caustic_hoff = r->local_shot_g;
     photon_pass_kind(r, 0, st);
     if (r->quota_c > 0) photon_pass_kind(r, 1, st); else { r->n_loc_c = 0; r->last_shot_c = 0; }
     if (st) {

@@ -1,11 +1,13 @@
 // sppm_render.hip — one SPPM iteration on the device: photon passes, map
 // builds, camera pass with gathers, resolve.
 //
-// Shape of the work (one wavefront stage per bounce, queues compacted between
-// bounces; every stage traces its own rays with the LDS-stack traversal):
-//   photon pass : k_photon_emit -> k_photon_bounce x depth -> scan -> k_photon_scatter
+// Shape of the work: a pass is one launch of a path kernel whose grid fills
+// the GPU once; each lane walks a whole path, bounce by bounce, and takes the
+// next unstarted path when its own ends (the LDS-stack traversal of
+// tk_bvh_device.h traces the rays):
+//   photon pass : k_photon_paths<KIND> -> scan -> k_photon_scatter
 //                 (tracePhoton / traceCausticPhoton, src/tracer/TkSppmTracer.cpp:104-217)
-//   camera pass : k_camera_gen -> k_camera_bounce x depth -> gathers
+//   camera pass : k_camera_paths -> gathers
 //                 (traceTile, src/tracer/TkSppmTracer.cpp:290-374)
 //   resolve     : k_resolve (src/tracer/TkSppmTracer.cpp:514-529)
 //
@@ -17,7 +19,9 @@
 // filled it, which is what a single CPU thread produces.
 #include <algorithm>
 #include <chrono>
-#include <future>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 
@@ -26,9 +30,7 @@
 
 namespace tkd {
 
-constexpr int kTailThreshold = 1 << 18;   // live paths at or below which a pass switches to its tail kernel
-
-enum { C_QA = 0, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */ };
+enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */ };
 
 // Everything one concurrently running pass needs: its stream, path state,
 // queues, counters and scratch.  Lane 0 traces the global photons and builds
@@ -37,22 +39,16 @@ enum { C_QA = 0, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS
 // them are bound by the latency of single rays, not by throughput.
 struct Lane {
     hipStream_t stream = nullptr;
-    DevBuf st_o, st_d, st_w, queue_a, queue_b, counters;
+    DevBuf counters;
+    int32_t* h_counters = nullptr;   // pinned host copy of the first counters
     DevBuf stage_pos, stage_pow, rec_count, rec_offset, prim_temp;
-    int ensure_paths(int64_t n) {
-        TK_TRY(st_o.ensure((size_t)n * 16));
-        TK_TRY(st_d.ensure((size_t)n * 16));
-        TK_TRY(st_w.ensure((size_t)n * 16));
-        TK_TRY(queue_a.ensure((size_t)n * 4));
-        TK_TRY(queue_b.ensure((size_t)n * 4));
-        return TKHIP_OK;
-    }
     void release() {
-        DevBuf* bufs[] = {&st_o, &st_d, &st_w, &queue_a, &queue_b, &counters, &stage_pos, &stage_pow, &rec_count,
-                          &rec_offset, &prim_temp};
+        DevBuf* bufs[] = {&counters, &stage_pos, &stage_pow, &rec_count, &rec_offset, &prim_temp};
         for (DevBuf* b : bufs) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
+        if (h_counters) (void)hipHostFree(h_counters);
+        h_counters = nullptr;
     }
 };
 
@@ -67,6 +63,7 @@ struct SppmState {
     DevBuf loc_pos[2], loc_pow[2], loc_dir[2];
     int64_t n_loc[2] = {0, 0}, last_shot[2] = {0, 0}, local_shot[2] = {0, 0}, shoot[2] = {0, 0};
     int64_t stored_c = 0;
+    int64_t caustic_hoff = 0;        // global paths shot before the current iteration
     double yield[2] = {2.0, 0.05};
     // pixels
     DevBuf planes, rows;
@@ -74,19 +71,13 @@ struct SppmState {
     int n_rows = 0;
     int64_t n_slots = 0;
     Lane lane[3];
+    int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
     DevBuf qbuf[2];
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
 };
 
-struct PathState {
-    float4* o;   // origin xyz; photon: u5 | camera: unused
-    float4* d;   // direction xyz; photon: u6 | camera: unused
-    float4* w;   // photon: power rgb, flags | camera: throughput rgb, flags (bit0 only-specular-so-far, bits 1.. sampler dim)
-};
-
 struct PhotonArgs {
     DScene sc;
-    PathState st;
     int32_t* rec_count;
     float4* stage_pos;   // xyz + direction bits
     float4* stage_pow;   // rgb
@@ -103,67 +94,60 @@ TKD uint64_t halton_index(const PhotonArgs& a, int slot) {
     return (uint64_t)(a.m0 + slot + a.hoff) * (uint64_t)a.world + (uint64_t)a.rank;
 }
 
-// Light choice, AreaLight::sample_Le and the initial power of a light path
-// (src/tracer/TkSppmTracer.cpp:106-122, src/Light.cpp:41-75,
-// src/Triangle.cpp:190-197).
-template <int KIND>
-__global__ void __launch_bounds__(256) k_photon_emit(PhotonArgs a, int64_t B, int32_t* queue, int32_t* counters) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    bool alive = false;
-    if (i < B) {
-        const DScene& sc = a.sc;
-        uint64_t H = halton_index(a, (int)i);
-        a.rec_count[i] = 0;
-        int nl = sc.n_lights;
-        if (nl > 0) {
-            int li = (int)(radical_inverse(0, H) * nl);
-            li = li > nl - 1 ? nl - 1 : li;
-            float pdf = 1.0f / nl;
-            float u0x = radical_inverse(1, H), u0y = radical_inverse(2, H);
-            float u1x = radical_inverse(3, H), u1y = radical_inverse(4, H);
-            float ubx = radical_inverse(5, H), uby = radical_inverse(6, H);
-            const DLight L = sc.lights[li];
-            float upick = photon_rng(a.seed, H, KIND, 0, 0);
-            float pd, tmp;
-            int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, upick, &pd);
-            LightPoint lp = tri_sample(sc, L.tri_first + idx, u0x, u0y, &tmp);
-            float pos_pdf = pd * tmp, dir_pdf;
-            F3 w;
-            if (L.two_sided) {
-                float ux = u1x;
-                if (ux < 0.5f) { ux = sse_min(ux * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); }
-                else { ux = sse_min((ux - 0.5f) * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); w.z *= -1; }
-                dir_pdf = 0.5f * (fabsf(w.z) * kInvPi);
-            } else {
-                w = cosine_hemisphere(u1x, u1y);
-                dir_pdf = w.z * kInvPi;
-            }
-            F3 v1, v2;
-            coordinate_system(lp.n, &v1, &v2);
-            w = add3(add3(scale3(v1, w.x), scale3(v2, w.y)), scale3(lp.n, w.z));
-            F3 o = offset_ray_origin(lp.p, lp.perr, lp.n, w);
-            F3 Le = light_L(L, lp.n, w);
-            if (!(pos_pdf == 0 || dir_pdf == 0)) {
-                F3 power = divs3(scale3(Le, absdot3(w, lp.n)), pos_pdf * dir_pdf * pdf);
-                a.st.o[i] = make_float4(o.x, o.y, o.z, ubx);
-                a.st.d[i] = make_float4(w.x, w.y, w.z, uby);
-                a.st.w[i] = make_float4(power.x, power.y, power.z, __int_as_float(0));
-                alive = true;
-            }
-        }
-    }
-    int dst = wave_append(&counters[C_QA], alive);
-    if (alive) queue[dst] = (int32_t)i;
-}
-
-// One bounce of a light path: closest hit, photon store at diffuse surfaces,
-// Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156 for the
-// global map, :179-216 for the caustic map).  Returns true while the path lives.
 struct PhotonPath {
     F3 o, d, power;
     float ubx, uby;
     int flags;
 };
+
+// Light choice, AreaLight::sample_Le and the initial power of light path i of
+// the batch (src/tracer/TkSppmTracer.cpp:106-122, src/Light.cpp:41-75,
+// src/Triangle.cpp:190-197).  False when the path carries no power.
+template <int KIND>
+TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
+    const DScene& sc = a.sc;
+    const uint64_t H = halton_index(a, i);
+    const int nl = sc.n_lights;
+    if (nl <= 0) return false;
+    int li = (int)(radical_inverse(0, H) * nl);
+    li = li > nl - 1 ? nl - 1 : li;
+    const float pdf = 1.0f / nl;
+    const float u0x = radical_inverse(1, H), u0y = radical_inverse(2, H);
+    const float u1x = radical_inverse(3, H), u1y = radical_inverse(4, H);
+    P.ubx = radical_inverse(5, H);
+    P.uby = radical_inverse(6, H);
+    const DLight L = sc.lights[li];
+    const float upick = photon_rng(a.seed, H, KIND, 0, 0);
+    float pd, tmp;
+    const int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, upick, &pd);
+    LightPoint lp = tri_sample(sc, L.tri_first + idx, u0x, u0y, &tmp);
+    const float pos_pdf = pd * tmp;
+    float dir_pdf;
+    F3 w;
+    if (L.two_sided) {
+        float ux = u1x;
+        if (ux < 0.5f) { ux = sse_min(ux * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); }
+        else { ux = sse_min((ux - 0.5f) * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); w.z *= -1; }
+        dir_pdf = 0.5f * (fabsf(w.z) * kInvPi);
+    } else {
+        w = cosine_hemisphere(u1x, u1y);
+        dir_pdf = w.z * kInvPi;
+    }
+    F3 v1, v2;
+    coordinate_system(lp.n, &v1, &v2);
+    w = add3(add3(scale3(v1, w.x), scale3(v2, w.y)), scale3(lp.n, w.z));
+    const F3 Le = light_L(L, lp.n, w);
+    if (pos_pdf == 0 || dir_pdf == 0) return false;
+    P.power = divs3(scale3(Le, absdot3(w, lp.n)), pos_pdf * dir_pdf * pdf);
+    P.o = offset_ray_origin(lp.p, lp.perr, lp.n, w);
+    P.d = w;
+    P.flags = 0;
+    return true;
+}
+
+// One bounce of a light path: closest hit, photon store at diffuse surfaces,
+// Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156 for the
+// global map, :179-216 for the caustic map).  Returns true while the path lives.
 template <int KIND, class STACK>
 TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, STACK stk) {
     const DScene& sc = a.sc;
@@ -175,11 +159,11 @@ TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, S
     bool diffuse = m.type == TK_DIFFUSE;
     if (KIND == 0) {
         if (diffuse) {
-            int c = a.rec_count[slot];
+            int c = P.flags;   // photons this path has staged so far
             int64_t at = (int64_t)slot * a.slots + c;
             a.stage_pos[at] = make_float4(sp.p.x, sp.p.y, sp.p.z, __uint_as_float(encode_direction(wo)));
             a.stage_pow[at] = make_float4(P.power.x, P.power.y, P.power.z, 0.f);
-            a.rec_count[slot] = c + 1;
+            P.flags = c + 1;
         }
     } else {
         if (!diffuse) P.flags |= 1;
@@ -203,60 +187,58 @@ TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, S
     P.d = wi;
     return bounce + 1 < a.depth;
 }
-TKD PhotonPath load_photon_path(const PhotonArgs& a, int slot) {
-    float4 so = a.st.o[slot], sd = a.st.d[slot], sw = a.st.w[slot];
-    PhotonPath P;
-    P.o = mk3(so.x, so.y, so.z); P.d = mk3(sd.x, sd.y, sd.z); P.power = mk3(sw.x, sw.y, sw.z);
-    P.ubx = so.w; P.uby = sd.w; P.flags = __float_as_int(sw.w);
-    return P;
+
+// Hands the idle lanes of a wave the next unstarted work items: returns this
+// lane's item or -1.  *exhausted turns true (for the whole wave) once the
+// cursor has passed n.  Every lane of the wave must call it.
+constexpr int kPathBlock = 64;   // one wave per block: the kernels below use wave-wide votes as barriers
+TKD int wave_fetch_work(int32_t* cursor, bool idle, int64_t n, bool* exhausted) {
+    const unsigned long long m = __ballot(idle);
+    const int want = __popcll(m);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, want);
+    base = __shfl(base, 0);
+    const int mine = base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    if ((int64_t)base + want >= n) *exhausted = true;
+    return (idle && mine < n) ? mine : -1;
 }
 
-// Wavefront stage: one bounce of every live path, survivors compacted into qout.
+// The photon pass of one batch of B light paths.  The grid is sized to fill
+// the GPU once; every lane walks one path at a time, bounce by bounce in step
+// with its wave, and a lane whose path has ended takes the next unstarted path
+// of the batch, so that waves stay full until the batch runs out.
 template <int KIND>
-__global__ void __launch_bounds__(256) k_photon_bounce(PhotonArgs a, int bounce, const int32_t* qin,
-                                                       const int32_t* count_in, int32_t* qout, int32_t* count_out,
-                                                       unsigned long long* rays) {
-    __shared__ int s_stack[kStackDepth * kTraceBlock];
-    LdsStack stk{&s_stack[threadIdx.x]};
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int n = *count_in;
-    bool go_on = false;
-    int slot = 0;
-    if (j < n) {
-        slot = qin[j];
-        PhotonPath P = load_photon_path(a, slot);
-        go_on = photon_step<KIND>(a, slot, bounce, P, stk);
-        if (go_on) {
-            a.st.o[slot] = make_float4(P.o.x, P.o.y, P.o.z, P.ubx);
-            a.st.d[slot] = make_float4(P.d.x, P.d.y, P.d.z, P.uby);
-            a.st.w[slot] = make_float4(P.power.x, P.power.y, P.power.z, __int_as_float(P.flags));
+__global__ void __launch_bounds__(kPathBlock) k_photon_paths(PhotonArgs a, int64_t B, int32_t* counters) {
+    __shared__ int s_stack[kStackDepth * kPathBlock];
+    LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
+    bool alive = false, exhausted = false;
+    int slot = 0, bounce = 0, traced = 0;
+    PhotonPath P{};
+    while (true) {
+        if (!exhausted && !__all(alive)) {
+            const int got = wave_fetch_work(&counters[C_QA], !alive, B, &exhausted);
+            if (got >= 0) {
+                slot = got; bounce = 0;
+                if (KIND == 1) a.rec_count[slot] = 0;
+                alive = photon_emit<KIND>(a, slot, P);
+                if (KIND == 0 && !alive) a.rec_count[slot] = 0;
+            }
+        }
+        if (!__any(alive)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (alive) {
+            ++traced;
+            alive = photon_step<KIND>(a, slot, bounce, P, stk);
+            ++bounce;
+            if (KIND == 0 && !alive) a.rec_count[slot] = P.flags;
         }
     }
-    int dst = wave_append(count_out, go_on);
-    if (go_on) qout[dst] = slot;
-    unsigned long long traced = __ballot(j < n);
-    if ((threadIdx.x & 63) == 0 && traced) atomicAdd(rays, (unsigned long long)__popcll(traced));
-}
-
-// Tail stage: once few paths are left a launch per bounce costs more than the
-// bounces themselves; each lane then walks its own path to the end.
-constexpr int kTailBlock = 64;
-template <int KIND>
-__global__ void __launch_bounds__(kTailBlock) k_photon_tail(PhotonArgs a, int bounce0, const int32_t* qin,
-                                                            const int32_t* count_in, unsigned long long* rays) {
-    __shared__ int s_stack[kStackDepth * kTailBlock];
-    LdsStackT<kTailBlock> stk{&s_stack[threadIdx.x]};
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int n = *count_in;
-    if (j >= n) return;
-    const int slot = qin[j];
-    PhotonPath P = load_photon_path(a, slot);
-    int traced = 0;
-    for (int b = bounce0; b < a.depth; ++b) {
-        ++traced;
-        if (!photon_step<KIND>(a, slot, b, P, stk)) break;
-    }
-    atomicAdd(rays, (unsigned long long)traced);
+    float wr = (float)traced;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
+    if ((threadIdx.x & 63) == 0 && wr > 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
 }
 
 // Appends the staged photons of the batch in path order behind the `base`
@@ -287,7 +269,6 @@ __global__ void k_photon_scatter(const int32_t* rec_count, const int32_t* rec_of
 struct CameraArgs {
     DScene sc;
     DCamera cam;
-    PathState st;
     const int32_t* rows;
     float* planes;
     int64_t n_pixels;
@@ -306,23 +287,21 @@ TKD Sampler make_sampler(const CameraArgs& a, int x, int y, int dim) {
     return s;
 }
 
-// src/tracer/TkSppmTracer.cpp:296-304
-__global__ void __launch_bounds__(256) k_camera_gen(CameraArgs a, int64_t n_slots, int32_t* queue) {
-    int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
-    int W = a.cam.w;
-    int y = a.rows[slot / W], x = (int)(slot % W);
+// The camera sample of slot `slot` of this rank's pixel rows
+// (src/tracer/TkSppmTracer.cpp:296-304).
+struct CameraPath {
+    F3 o, d, coef;
+    int flags;     // bit0: only specular surfaces so far; bits 1..: sampler dimension
+};
+TKD void camera_start(const CameraArgs& a, int x, int y, CameraPath& P) {
     Sampler sm = make_sampler(a, x, y, 0);
     float cx, cy, lx, ly;
     sampler_get2d(sm, &cx, &cy);
     cx = cx + (float)x; cy = cy + (float)y;
     sampler_get2d(sm, &lx, &ly);   // lens sample: drawn and unused with a pinhole camera
-    F3 o, d;
-    camera_ray(a.cam, cx, cy, &o, &d);
-    a.st.o[slot] = make_float4(o.x, o.y, o.z, 0.f);
-    a.st.d[slot] = make_float4(d.x, d.y, d.z, 0.f);
-    a.st.w[slot] = make_float4(1.f, 1.f, 1.f, __int_as_float(1 | (sm.dim << 1)));
-    queue[slot] = (int32_t)slot;
+    camera_ray(a.cam, cx, cy, &P.o, &P.d);
+    P.coef = mk3(1.f, 1.f, 1.f);
+    P.flags = 1 | (sm.dim << 1);
 }
 
 TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp, F3 coef, const TkMaterial& m,
@@ -337,10 +316,6 @@ TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp
 // src/tracer/TkSppmTracer.cpp:306-371, with Scene::uniformSampleOneLight,
 // src/core/Scene.cpp:43-61, inlined).  Gather queries are reported through
 // want_cq / want_gq together with the surface they belong to.
-struct CameraPath {
-    F3 o, d, coef;
-    int flags;     // bit0: only specular surfaces so far; bits 1..: sampler dimension
-};
 struct CameraStepOut {
     bool want_cq, want_gq;
     SurfacePoint sp;
@@ -437,63 +412,35 @@ TKD void count_rays(int32_t* counters, int nrays) {
         atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
 }
 
-__global__ void __launch_bounds__(256) k_camera_bounce(CameraArgs a, int bounce, const int32_t* qin,
-                                                       const int32_t* count_in, int32_t* qout, int32_t* counters,
-                                                       int out_counter) {
-    __shared__ int s_stack[kStackDepth * kTraceBlock];
-    LdsStack stk{&s_stack[threadIdx.x]};
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int n = *count_in;
-    bool go_on = false;
-    int slot = 0, pixel = 0;
-    CameraStepOut so{};
-    if (j < n) {
-        slot = qin[j];
-        const int W = a.cam.w;
-        const int y = a.rows[slot / W], x = slot % W;
-        pixel = x + y * W;
-        float4 po = a.st.o[slot], pd = a.st.d[slot], pw = a.st.w[slot];
-        CameraPath P;
-        P.o = mk3(po.x, po.y, po.z); P.d = mk3(pd.x, pd.y, pd.z); P.coef = mk3(pw.x, pw.y, pw.z);
-        P.flags = __float_as_int(pw.w);
-        go_on = camera_step(a, x, y, pixel, bounce, P, so, stk);
-        if (go_on) {
-            a.st.o[slot] = make_float4(P.o.x, P.o.y, P.o.z, 0.f);
-            a.st.d[slot] = make_float4(P.d.x, P.d.y, P.d.z, 0.f);
-            a.st.w[slot] = make_float4(P.coef.x, P.coef.y, P.coef.z, __int_as_float(P.flags));
-        }
-    }
-    camera_emit_queries(a, counters, so, pixel);
-    int dst = wave_append(&counters[out_counter], go_on);
-    if (go_on) qout[dst] = slot;
-    count_rays(counters, so.nrays);
-}
-
-// Tail stage of the camera pass: the few paths still bouncing between specular
-// surfaces are walked to their end by one lane each.
-__global__ void __launch_bounds__(kTailBlock) k_camera_tail(CameraArgs a, int bounce0, const int32_t* qin,
-                                                            const int32_t* count_in, int32_t* counters) {
-    __shared__ int s_stack[kStackDepth * kTailBlock];
-    LdsStackT<kTailBlock> stk{&s_stack[threadIdx.x]};
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int n = *count_in;
-    bool alive = j < n;
-    int slot = 0, pixel = 0, x = 0, y = 0, nrays = 0;
+// The camera pass of this rank's pixels, organised like k_photon_paths: lanes
+// that finish a path start the next unstarted pixel.
+__global__ void __launch_bounds__(kPathBlock) k_camera_paths(CameraArgs a, int64_t n_slots, int32_t* counters) {
+    __shared__ int s_stack[kStackDepth * kPathBlock];
+    LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
+    bool alive = false, exhausted = false;
+    int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
     CameraPath P{};
-    if (alive) {
-        slot = qin[j];
-        const int W = a.cam.w;
-        y = a.rows[slot / W]; x = slot % W;
-        pixel = x + y * W;
-        float4 po = a.st.o[slot], pd = a.st.d[slot], pw = a.st.w[slot];
-        P.o = mk3(po.x, po.y, po.z); P.d = mk3(pd.x, pd.y, pd.z); P.coef = mk3(pw.x, pw.y, pw.z);
-        P.flags = __float_as_int(pw.w);
-    }
-    for (int b = bounce0; b < a.depth && __any(alive); ++b) {
+    const int W = a.cam.w;
+    while (true) {
+        if (!exhausted && !__all(alive)) {
+            const int got = wave_fetch_work(&counters[C_QA], !alive, n_slots, &exhausted);
+            if (got >= 0) {
+                y = a.rows[got / W]; x = got % W;
+                pixel = x + y * W;
+                bounce = 0;
+                camera_start(a, x, y, P);
+                alive = true;
+            }
+        }
+        if (!__any(alive)) {
+            if (exhausted) break;
+            continue;
+        }
         CameraStepOut so{};
         if (alive) {
-            alive = camera_step(a, x, y, pixel, b, P, so, stk);
+            alive = camera_step(a, x, y, pixel, bounce, P, so, stk);
             nrays += so.nrays;
+            ++bounce;
         }
         camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
     }
@@ -567,89 +514,95 @@ static int read_u64_counter(Lane& l, int at, int64_t* out) {
     return TKHIP_OK;
 }
 
-// The photon pass of one map on its lane.  Returns with the lane's stream idle.
+// Enqueues one batch of light paths of a photon pass on its lane: the path
+// kernel, the scan over the per-path photon counts, the scatter into the local
+// store and the read-back of the batch counters.  Nothing is waited for.
 template <int KIND>
-static int photon_pass_kind(tkhip_ctx* ctx) {
+static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int64_t* B_out) {
     SppmState* s = ctx->sppm;
     Lane& ln = s->lane[KIND];
     hipStream_t stream = ln.stream;
     const int64_t quota = s->quota[KIND];
-    int64_t stored = 0, shot = 0;
     const int slots = KIND == 0 ? s->max_depth : 1;
     const int depth = KIND == 0 ? s->max_depth : 64;
     int32_t* counters = ln.counters.as<int32_t>();
+    const int64_t need = quota - stored;
+    int64_t B = (int64_t)((double)need / s->yield[KIND] * 1.02) + 256;
+    B = std::min<int64_t>(B, (int64_t)1 << 24);
+    TK_TRY(ln.stage_pos.ensure((size_t)B * slots * 16));
+    TK_TRY(ln.stage_pow.ensure((size_t)B * slots * 16));
+    TK_TRY(ln.rec_count.ensure((size_t)B * 4));
+    TK_TRY(ln.rec_offset.ensure((size_t)B * 4));
+    PhotonArgs a;
+    a.sc = ctx->scene;
+    a.rec_count = ln.rec_count.as<int32_t>();
+    a.stage_pos = ln.stage_pos.as<float4>();
+    a.stage_pow = ln.stage_pow.as<float4>();
+    a.m0 = s->local_shot[KIND] + shot;
+    // caustic index = j + shootGlobalPhotons (TkSppmTracer.cpp:419), the global count taken at the
+    // start of the iteration so that the two passes do not depend on each other
+    a.hoff = KIND == 0 ? 0 : s->caustic_hoff;
+    a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
+    TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
+    const int waves = (int)std::min<int64_t>(divup(B, kPathBlock), s->path_waves[KIND]);
+    k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, B, counters);
+    TK_LAUNCH_CHECK();
+    TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
+    k_photon_scatter<<<divup(B, 256), 256, 0, stream>>>(ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(),
+                                                        ln.stage_pos.as<float4>(), ln.stage_pow.as<float4>(), slots, B, stored,
+                                                        quota, s->loc_pos[KIND].as<float>(), s->loc_pow[KIND].as<float>(),
+                                                        s->loc_dir[KIND].as<uint16_t>(), counters);
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 6 * 4, hipMemcpyDeviceToHost, stream));
+    *B_out = B;
+    return TKHIP_OK;
+}
+
+// Start of a photon pass: clears the ray counter and enqueues the first batch.
+template <int KIND>
+static int photon_pass_begin(tkhip_ctx* ctx, int64_t* B_out) {
+    SppmState* s = ctx->sppm;
+    Lane& ln = s->lane[KIND];
+    *B_out = 0;
+    if (s->quota[KIND] <= 0) return TKHIP_OK;
+    TK_HIP(hipMemsetAsync(&ln.counters.as<int32_t>()[C_RAYS], 0, 8, ln.stream));
+    return photon_launch_batch<KIND>(ctx, 0, 0, B_out);
+}
+
+// Rest of the pass: takes the result of the batch in flight and enqueues
+// further batches until the quota is met.  Returns with the lane's stream idle.
+template <int KIND>
+static int photon_pass_finish(tkhip_ctx* ctx, int64_t B) {
+    SppmState* s = ctx->sppm;
+    Lane& ln = s->lane[KIND];
+    const int64_t quota = s->quota[KIND];
+    int64_t stored = 0, shot = 0;
     const int64_t emitted_cap = KIND == 0 ? (int64_t)1 << 40 : quota * 4000 + 100000;
-    int32_t host_counters[16];
-    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
-    while (stored < quota && shot < emitted_cap) {
-        int64_t need = quota - stored;
-        int64_t B = (int64_t)((double)need / s->yield[KIND] * 1.02) + 256;
-        B = std::min<int64_t>(B, (int64_t)1 << 24);
-        TK_TRY(ln.ensure_paths(B));
-        TK_TRY(ln.stage_pos.ensure((size_t)B * slots * 16));
-        TK_TRY(ln.stage_pow.ensure((size_t)B * slots * 16));
-        TK_TRY(ln.rec_count.ensure((size_t)B * 4));
-        TK_TRY(ln.rec_offset.ensure((size_t)B * 4));
-        PhotonArgs a;
-        a.sc = ctx->scene;
-        a.st = PathState{ln.st_o.as<float4>(), ln.st_d.as<float4>(), ln.st_w.as<float4>()};
-        a.rec_count = ln.rec_count.as<int32_t>();
-        a.stage_pos = ln.stage_pos.as<float4>();
-        a.stage_pow = ln.stage_pow.as<float4>();
-        a.m0 = s->local_shot[KIND] + shot;
-        a.hoff = KIND == 0 ? 0 : s->local_shot[0];   // caustic index = j + shootGlobalPhotons (TkSppmTracer.cpp:419)
-        a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
-        TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
-        int32_t* qa = ln.queue_a.as<int32_t>();
-        int32_t* qb = ln.queue_b.as<int32_t>();
-        const int grid = divup(B, 256);
-        k_photon_emit<KIND><<<grid, 256, 0, stream>>>(a, B, qa, counters);
-        TK_LAUNCH_CHECK();
-        int64_t live_bound = B;
-        int ca = C_QA, cb = C_QB;
-        unsigned long long* rays = reinterpret_cast<unsigned long long*>(&counters[C_RAYS]);
-        for (int b = 0; b < depth; ++b) {
-            TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
-            k_photon_bounce<KIND><<<divup(live_bound, 256), 256, 0, stream>>>(a, b, qa, &counters[ca], qb, &counters[cb], rays);
-            TK_LAUNCH_CHECK();
-            std::swap(qa, qb);
-            std::swap(ca, cb);
-            if (b + 1 < depth && (b == 1 || b == 3 || b == 7 || b == 15 || b == 31)) {
-                // look at the live count now and then: stop when no path is left, hand a short
-                // queue to the tail kernel, otherwise shrink the next launches
-                int32_t live = 0;
-                TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
-                TK_HIP(hipStreamSynchronize(stream));
-                if (live == 0) break;
-                if (live <= kTailThreshold) {
-                    k_photon_tail<KIND><<<divup(live, kTailBlock), kTailBlock, 0, stream>>>(a, b + 1, qa, &counters[ca], rays);
-                    TK_LAUNCH_CHECK();
-                    break;
-                }
-                live_bound = live;
-            }
-        }
-        TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
-        k_photon_scatter<<<grid, 256, 0, stream>>>(ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(),
-                                                   ln.stage_pos.as<float4>(), ln.stage_pow.as<float4>(), slots, B, stored,
-                                                   quota, s->loc_pos[KIND].as<float>(), s->loc_pow[KIND].as<float>(),
-                                                   s->loc_dir[KIND].as<uint16_t>(), counters);
-        TK_LAUNCH_CHECK();
-        TK_HIP(hipMemcpyAsync(host_counters, counters, 6 * 4, hipMemcpyDeviceToHost, stream));
-        TK_HIP(hipStreamSynchronize(stream));
-        int64_t total = host_counters[C_TOTAL];
-        int64_t got = std::min<int64_t>(total, need);
-        int64_t used = total >= need ? host_counters[C_USED] : B;
+    while (B > 0) {
+        TK_HIP(hipStreamSynchronize(ln.stream));
+        const int64_t need = quota - stored;
+        const int64_t total = ln.h_counters[C_TOTAL];
+        const int64_t got = std::min<int64_t>(total, need);
+        const int64_t used = total >= need ? ln.h_counters[C_USED] : B;
         stored += got;
         shot += used;
         if (used > 0 && got > 0) s->yield[KIND] = 0.5 * s->yield[KIND] + 0.5 * ((double)got / (double)used);
         else if (got == 0) s->yield[KIND] *= 0.25;
         s->yield[KIND] = std::max(s->yield[KIND], 1e-4);
+        B = 0;
+        if (stored < quota && shot < emitted_cap) TK_TRY(photon_launch_batch<KIND>(ctx, stored, shot, &B));
     }
     s->n_loc[KIND] = stored;
     s->last_shot[KIND] = shot;
     s->local_shot[KIND] += shot;
     return TKHIP_OK;
+}
+
+template <int KIND>
+static int photon_pass_kind(tkhip_ctx* ctx) {
+    int64_t B = 0;
+    TK_TRY(photon_pass_begin<KIND>(ctx, &B));
+    return photon_pass_finish<KIND>(ctx, B);
 }
 
 static int install_map(tkhip_ctx* ctx, int which, const float* pos, const float* pow, const uint16_t* dir, int64_t n,
@@ -679,7 +632,6 @@ static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     if (s->n_slots == 0) return TKHIP_OK;
     CameraArgs a;
     a.sc = ctx->scene; a.cam = ctx->cam;
-    a.st = PathState{ln.st_o.as<float4>(), ln.st_d.as<float4>(), ln.st_w.as<float4>()};
     a.rows = s->rows.as<int32_t>();
     a.planes = s->planes.as<float>();
     a.n_pixels = s->n_pixels;
@@ -691,38 +643,13 @@ static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.qcap = s->n_slots;
     TK_HIP(hipMemsetAsync(counters, 0, 4 * 4, stream));
     TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
-    int32_t* qa = ln.queue_a.as<int32_t>();
-    int32_t* qb = ln.queue_b.as<int32_t>();
-    k_camera_gen<<<divup(s->n_slots, 256), 256, 0, stream>>>(a, s->n_slots, qa);
-    int32_t nslots32 = (int32_t)s->n_slots;
-    TK_HIP(hipMemcpyAsync(&counters[C_QA], &nslots32, 4, hipMemcpyHostToDevice, stream));
+    const int waves = (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
+    k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, s->n_slots, counters);
     TK_LAUNCH_CHECK();
-    int64_t live_bound = s->n_slots;
-    int ca = C_QA, cb = C_QB;
-    for (int b = 0; b < s->max_depth; ++b) {
-        TK_HIP(hipMemsetAsync(&counters[cb], 0, 4, stream));
-        k_camera_bounce<<<divup(live_bound, 256), 256, 0, stream>>>(a, b, qa, &counters[ca], qb, counters, cb);
-        TK_LAUNCH_CHECK();
-        std::swap(qa, qb);
-        std::swap(ca, cb);
-        if (b + 1 < s->max_depth && (b == 1 || b == 3 || b == 7 || b == 15 || b == 31)) {
-            int32_t live = 0;
-            TK_HIP(hipMemcpyAsync(&live, &counters[ca], 4, hipMemcpyDeviceToHost, stream));
-            TK_HIP(hipStreamSynchronize(stream));
-            if (live == 0) break;
-            if (live <= kTailThreshold) {
-                k_camera_tail<<<divup(live, kTailBlock), kTailBlock, 0, stream>>>(a, b + 1, qa, &counters[ca], counters);
-                TK_LAUNCH_CHECK();
-                break;
-            }
-            live_bound = live;
-        }
-    }
-    int32_t hc[4];
-    TK_HIP(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, stream));
+    TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
     TK_HIP(hipStreamSynchronize(stream));
-    s->n_queries[0] = hc[C_NGQ];
-    s->n_queries[1] = hc[C_NCQ];
+    s->n_queries[0] = ln.h_counters[C_NGQ];
+    s->n_queries[1] = ln.h_counters[C_NCQ];
     return TKHIP_OK;
 }
 
@@ -871,7 +798,29 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
         if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio[lane_no++]) != hipSuccess) { set_error("tkhip_sppm_begin: hipStreamCreate failed"); rc = TKHIP_E_HIP; break; }
         rc = l.counters.ensure(64);
         if (rc) break;
+        if (hipHostMalloc(reinterpret_cast<void**>(&l.h_counters), 64, hipHostMallocDefault) != hipSuccess) { set_error("tkhip_sppm_begin: pinned allocation failed"); rc = TKHIP_E_NOMEM; break; }
+        std::memset(l.h_counters, 0, 64);
         if (hipMemsetAsync(l.counters.p, 0, 64, l.stream) != hipSuccess) { set_error("tkhip_sppm_begin: memset failed"); rc = TKHIP_E_HIP; break; }
+    }
+    if (!rc) {
+        hipDeviceProp_t prop{};
+        int per_cu[3] = {0, 0, 0};
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k_photon_paths<0>, kPathBlock, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k_photon_paths<1>, kPathBlock, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[2], k_camera_paths, kPathBlock, 0) != hipSuccess) {
+            set_error("tkhip_sppm_begin: occupancy query failed");
+            rc = TKHIP_E_HIP;
+        } else {
+            const char* ov = getenv("TKHIP_PATH_WAVES_PER_CU");   // tuning aid
+            for (int l = 0; l < 3; ++l) {
+                if (ov && atoi(ov) > 0) per_cu[l] = atoi(ov);
+                s->path_waves[l] = std::max(per_cu[l], 1) * std::max(prop.multiProcessorCount, 1);
+            }
+            if (getenv("TKHIP_VERBOSE"))
+                fprintf(stderr, "tkhip: path kernels resident waves per CU: %d %d %d on %d CUs\n", per_cu[0], per_cu[1], per_cu[2],
+                        prop.multiProcessorCount);
+        }
     }
     if (!rc) rc = map_create(ctx, param->globalSize, param->globalSample, &s->map[0]);
     if (!rc) rc = map_create(ctx, std::max(param->causticSize, 1), param->causticSample, &s->map[1]);
@@ -895,7 +844,6 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     s->n_slots = (int64_t)s->n_rows * W;
     if (!rc) rc = s->planes.ensure((size_t)s->n_pixels * 13 * 4);
     if (!rc) rc = s->rows.ensure(std::max<size_t>(rows.size(), 1) * 4);
-    if (!rc) rc = s->lane[2].ensure_paths(std::max<int64_t>(s->n_slots, 1));
     for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
     if (rc) { destroy_sppm(ctx); return rc; }
     if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -911,9 +859,12 @@ int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     (void)iter;
     SppmState* s = ctx->sppm;
     double t0 = now_ms();
-    TK_TRY(photon_pass_kind<0>(ctx));
-    if (s->quota[1] > 0) TK_TRY(photon_pass_kind<1>(ctx));
-    else { s->n_loc[1] = 0; s->last_shot[1] = 0; }
+    s->caustic_hoff = s->local_shot[0];
+    int64_t Bg = 0, Bc = 0;
+    TK_TRY(photon_pass_begin<0>(ctx, &Bg));      // both passes are in flight together
+    TK_TRY(photon_pass_begin<1>(ctx, &Bc));
+    TK_TRY(photon_pass_finish<0>(ctx, Bg));
+    TK_TRY(photon_pass_finish<1>(ctx, Bc));
     if (s->world == 1) {
         TK_TRY(install_local(ctx, 0));
         TK_TRY(install_local(ctx, 1));
@@ -981,10 +932,10 @@ int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
 
 // One iteration on a single GPU.  The camera paths do not read the photon
 // maps until they gather, so three things run side by side: the global photon
-// pass followed by the global tree build, the caustic photon pass (it starts
-// when the global pass has fixed its Halton offset) followed by the caustic
-// tree build, and the camera paths.  The gathers of both maps follow, again
-// side by side.  The per-phase times of the stats therefore overlap.
+// pass followed by the global tree build, the caustic photon pass followed by
+// the caustic tree build, and the camera paths.  The gathers of both maps
+// follow, again side by side.  The per-phase times of the stats therefore
+// overlap.
 int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_iteration");
     SppmState* s = ctx->sppm;
@@ -992,15 +943,17 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
                "tkhip_sppm_iteration: with world > 1 drive the passes and the photon exchange separately");
     const double t0 = now_ms();
     double t_photon_end[2] = {t0, t0}, build_ms[2] = {0, 0};
-    std::promise<int> global_pass_done;
-    std::future<int> global_pass_rc = global_pass_done.get_future();
+    // Enqueue in the order of the critical path: the global pass (the longest chain: pass, then
+    // the larger tree), the caustic pass, the camera paths.  Each then fills what the others leave.
+    s->caustic_hoff = s->local_shot[0];
+    int64_t Bg = 0, Bc = 0;
+    TK_TRY(photon_pass_begin<0>(ctx, &Bg));
+    TK_TRY(photon_pass_begin<1>(ctx, &Bc));
     Worker wg, wc;
     wg.start(ctx, [&, ctx, s]() {
-        int rc = photon_pass_kind<0>(ctx);
-        if (rc == TKHIP_OK) rc = install_local(ctx, 0);
+        TK_TRY(photon_pass_finish<0>(ctx, Bg));
+        TK_TRY(install_local(ctx, 0));
         t_photon_end[0] = now_ms();
-        global_pass_done.set_value(rc);
-        if (rc != TKHIP_OK) return rc;
         double b0 = now_ms();
         TK_TRY(map_build(s->map[0]));
         TK_HIP(hipStreamSynchronize(s->map[0]->stream));
@@ -1008,9 +961,7 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         return TKHIP_OK;
     });
     wc.start(ctx, [&, ctx, s]() {
-        if (global_pass_rc.get() != TKHIP_OK) return TKHIP_OK;   // the global worker reports its own failure
-        if (s->quota[1] > 0) TK_TRY(photon_pass_kind<1>(ctx));
-        else { s->n_loc[1] = 0; s->last_shot[1] = 0; }
+        TK_TRY(photon_pass_finish<1>(ctx, Bc));
         TK_TRY(install_local(ctx, 1));
         TK_HIP(hipStreamSynchronize(s->map[1]->stream));
         t_photon_end[1] = now_ms();

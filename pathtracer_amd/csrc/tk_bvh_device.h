@@ -183,6 +183,12 @@ TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int64_t* nprim
 // Closest hit (ANY_HIT = false) or occlusion (ANY_HIT = true: stops at the
 // first hit below tmax, enough for the boolean Scene::intersectP answers,
 // src/core/Scene.cpp:27-31).
+//
+// Two nested loops: the inner one only walks inner nodes (two slab tests and a
+// push), and a lane leaves it when it holds a leaf; the primitive tests of the
+// leaf then run once the whole wave is out of the inner loop, with most lanes
+// taking part, instead of a few lanes at a time in the middle of the descent.
+// Stack entries are inner nodes (>= 0) or leaves (< 0, ~encoding).
 template <bool ANY_HIT, class STACK>
 TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, STACK st) {
     Hit h;
@@ -192,34 +198,39 @@ TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, STACK st) {
         return h;
     }
     // Ray ctor: direction_inv = float(1.0 / double(dir)) (src/Ray.hpp:21)
-    F3 dinv = mk3((float)(1. / (double)d.x), (float)(1. / (double)d.y), (float)(1. / (double)d.z));
+    const F3 dinv = mk3((float)(1. / (double)d.x), (float)(1. / (double)d.y), (float)(1. / (double)d.z));
+    constexpr int kDone = 0x7fffffff;
     int sp = 0;
-    int node = 0;
+    int cur = 0;
+    float tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
     while (true) {
-        const BvhNode nd = sc.nodes[node];
-        float tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
-        float tl, tr;
-        bool hl = box_hit(nd.lmin, nd.lmax, o, dinv, tcull, &tl);
-        bool hr = box_hit(nd.rmin, nd.rmax, o, dinv, tcull, &tr);
-        int near = nd.left, far = nd.right;
-        if (hl && hr && tr < tl) { near = nd.right; far = nd.left; }
-        else if (!hl) { near = nd.right; far = nd.left; }
-        int next = -1;
-        bool have_next = false;
-        if (hl || hr) {
-            if (near < 0) leaf_test<ANY_HIT>(sc, ~near, o, d, &h, nullptr);
-            else { next = near; have_next = true; }
+        while ((unsigned)cur < (unsigned)kDone) {
+            const BvhNode nd = sc.nodes[cur];
+            float tl, tr;
+            const bool hl = box_hit(nd.lmin, nd.lmax, o, dinv, tcull, &tl);
+            const bool hr = box_hit(nd.rmin, nd.rmax, o, dinv, tcull, &tr);
             if (hl && hr) {
-                if (far < 0) leaf_test<ANY_HIT>(sc, ~far, o, d, &h, nullptr);
-                else if (have_next) { st.push(sp, far); ++sp; }
-                else { next = far; have_next = true; }
+                const bool right_first = tr < tl;
+                st.push(sp, right_first ? nd.left : nd.right);
+                ++sp;
+                cur = right_first ? nd.right : nd.left;
+            } else if (hl) {
+                cur = nd.left;
+            } else if (hr) {
+                cur = nd.right;
+            } else if (sp > 0) {
+                --sp;
+                cur = st.pop(sp);
+            } else {
+                cur = kDone;
             }
         }
+        if (cur == kDone) break;
+        leaf_test<ANY_HIT>(sc, ~cur, o, d, &h, nullptr);
         if (ANY_HIT && h.prim >= 0) return h;
-        if (have_next) { node = next; continue; }
-        if (sp == 0) break;
-        --sp;
-        node = st.pop(sp);
+        tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
+        if (sp > 0) { --sp; cur = st.pop(sp); }
+        else cur = kDone;
     }
     return h;
 }
