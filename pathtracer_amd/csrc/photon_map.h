@@ -1,10 +1,10 @@
-// photon_map.h — device photon map: storage, sort-based KD-tree, kNN gather.
+// photon_map.h — device photon map: storage, search tree, kNN gather.
 #pragma once
 #include "tk_common.h"
 
 namespace tkd {
 
-constexpr int kLeafCap = 32;   // photons per KD leaf (at most; at least half)
+constexpr int kLeafCap = 32;   // photons per tree leaf (at most; at least half)
 
 // Queries of one gather launch, struct-of-arrays on the device.
 struct QueryView {
@@ -46,9 +46,8 @@ struct tkhip_map {
     int k = 0;
     bool built = false;
     int nl = 0, depth = 0;
-    float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
     tkd::DevBuf in_pos, in_pow, in_dir;            // storage order: float3, float3, u16
-    tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
+    tkd::DevBuf pos4, pow4, node_box;
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
     float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)

@@ -1,10 +1,14 @@
 // photon_map.hip — the photon map on the device.
 //
 //  * storage  : PhotonMap::storePhoton (src/tracer/Photonmap.cpp:44-53)
-//  * build    : PhotonMap::buildKdTree / balance (src/tracer/Photonmap.cpp:96-103, :132-179)
-//               as a sort-based median split: per level one radix sort of
-//               (node id, coordinate on the node's widest axis) keys; the tree
-//               is implicit (complete binary tree, photon ranges by arithmetic)
+//  * build    : the search structure PhotonMap::buildKdTree / balance make
+//               (src/tracer/Photonmap.cpp:96-103, :132-179), here a balanced
+//               binary tree over the photons in Hilbert-curve order: one radix
+//               sort, leaves are equal runs of at most kLeafCap consecutive
+//               photons, the tree above them is implicit (complete binary
+//               tree, photon ranges by arithmetic) and every node carries the
+//               tight box of its photons.  A gather's result does not depend
+//               on the shape of the tree.
 //  * gather   : neighbor_search + radiance_estimate (src/tracer/neighbor.cpp:5-85,
 //               src/tracer/Photonmap.cpp:105-130) with the fused per-pixel update of
 //               traceTile (src/tracer/TkSppmTracer.cpp:327-340, :346-359)
@@ -62,78 +66,75 @@ TKD int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 TKD float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // ---------------------------------------------------------------- build
-__global__ void k_iota(uint32_t* a, int64_t n) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) a[i] = (uint32_t)i;
-}
-
-__global__ void k_root_box_init(uint32_t* box6) {
+// Bounds of the photons: block-wide min / max, then one atomic per block and
+// component on order-preserving integer images of the floats.
+__global__ void k_bounds_init(uint32_t* box6) {
     if (threadIdx.x < 3) box6[threadIdx.x] = 0xffffffffu;
     else if (threadIdx.x < 6) box6[threadIdx.x] = 0u;
 }
-__global__ void k_root_box(const float* pos, int64_t n, uint32_t* box6) {
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+__global__ void __launch_bounds__(256) k_bounds(const float* pos, int64_t n, uint32_t* box6) {
+    __shared__ float s_red[6][4];
+    float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         for (int a = 0; a < 3; ++a) {
-            float v = pos[3 * i + a];
-            mn[a] = fminf(mn[a], v);
-            mx[a] = fmaxf(mx[a], v);
+            float x = pos[3 * i + a];
+            v[a] = fminf(v[a], x);
+            v[3 + a] = fmaxf(v[3 + a], x);
         }
-    for (int a = 0; a < 3; ++a) {
-        float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&box6[a], f2ord(lo));
-            atomicMax(&box6[3 + a], f2ord(hi));
-        }
+    for (int a = 0; a < 3; ++a) { v[a] = wave_min(v[a]); v[3 + a] = wave_max(v[3 + a]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 6; ++a) s_red[a][threadIdx.x >> 6] = v[a];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float r = s_red[a][0];
+        for (int w = 1; w < 4; ++w) r = a < 3 ? fminf(r, s_red[a][w]) : fmaxf(r, s_red[a][w]);
+        if (a < 3) atomicMin(&box6[a], f2ord(r));
+        else atomicMax(&box6[a], f2ord(r));
     }
 }
-// clip_box: 6 floats per heap node (min xyz, max xyz); node 1 is the root.
-__global__ void k_root_finish(const uint32_t* box6, float* clip_box) {
-    if (threadIdx.x < 6) clip_box[6 + threadIdx.x] = ord2f(box6[threadIdx.x]);
-}
 
-// Bounds3::maxExtent on the clipped node box (src/Bounds3.hpp:32-41,
-// src/tracer/Photonmap.cpp:136, :149-152, :167-170)
-__global__ void k_level_axis(const float* clip_box, int32_t* node_axis, int level) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int count = 1 << level;
-    if (j >= count) return;
-    int node = count + j;
-    const float* b = clip_box + 6 * (int64_t)node;
-    float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
-    int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
-    node_axis[node] = axis;
+// Position of a query along a 3-D Hilbert curve through the photon bounds
+// (10 bits per axis, Skilling's transpose form).  Unlike a Morton curve a
+// Hilbert curve has no jumps: consecutive queries in this order are always
+// neighbours in space, so the search boxes of the 64 queries of a wave overlap.
+TKD uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t X[3] = {x, y, z};
+    const uint32_t M = 1u << 9;
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        uint32_t P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    uint32_t key = 0;
+#pragma unroll
+    for (int b = 9; b >= 0; --b) {
+        key = (key << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+    }
+    return key;
 }
-
-__global__ void k_level_keys(const float* pos, const uint32_t* idx, const int32_t* node_axis, uint64_t* keys,
-                             int64_t n, int nl, int depth, int level) {
+// Hilbert key of every photon inside the photon bounds (10 bits per axis).
+__global__ void k_photon_curve(const float* pos, int64_t n, const uint32_t* box6, uint32_t* keys, uint32_t* vals) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int leaf = leaf_of_pos(i, n, nl);
-    int j = leaf >> (depth - level);
-    int axis = node_axis[(1 << level) + j];
-    float v = pos[3 * (int64_t)idx[i] + axis];
-    keys[i] = ((uint64_t)(uint32_t)j << 32) | f2ord(v);
-}
-
-// The median photon (first of the right half) fixes the split plane; children
-// inherit the parent box clipped at it.
-__global__ void k_level_split(const float* pos, const uint32_t* idx, float* clip_box, const int32_t* node_axis,
-                              int64_t n, int nl, int depth, int level) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int count = 1 << level;
-    if (j >= count) return;
-    int node = count + j;
-    int axis = node_axis[node];
-    int mid_leaf = (2 * j + 1) << (depth - level - 1);
-    int64_t mid = leaf_start(mid_leaf, n, nl);
-    float split = pos[3 * (int64_t)idx[mid] + axis];
-    const float* b = clip_box + 6 * (int64_t)node;
-    float* l = clip_box + 6 * (int64_t)(2 * node);
-    float* r = clip_box + 6 * (int64_t)(2 * node + 1);
-    for (int a = 0; a < 6; ++a) { l[a] = b[a]; r[a] = b[a]; }
-    l[3 + axis] = split;
-    r[axis] = split;
+    float q[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = ord2f(box6[a]), hi = ord2f(box6[3 + a]);
+        float e = hi - lo;
+        float inv = e > 0 ? 1023.f / e : 0.f;
+        q[a] = fminf(fmaxf((pos[3 * i + a] - lo) * inv, 0.f), 1023.f);
+    }
+    keys[i] = hilbert30((uint32_t)q[0], (uint32_t)q[1], (uint32_t)q[2]);
+    vals[i] = (uint32_t)i;
 }
 
 __global__ void k_permute(const float* pos, const float* pow, const uint16_t* dir, const uint32_t* idx,
@@ -161,15 +162,20 @@ __global__ void k_leaf_boxes(const float4* pos4, float4* node_box, int64_t n, in
     node_box[2 * (int64_t)node] = make_float4(mn[0], mn[1], mn[2], mx[0]);
     node_box[2 * (int64_t)node + 1] = make_float4(mx[1], mx[2], 0.f, 0.f);
 }
-__global__ void k_inner_boxes(float4* node_box, int level) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int count = 1 << level;
-    if (j >= count) return;
-    int64_t node = count + j;
-    float4 a0 = node_box[4 * node], a1 = node_box[4 * node + 1];
-    float4 b0 = node_box[4 * node + 2], b1 = node_box[4 * node + 3];
-    node_box[2 * node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
-    node_box[2 * node + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), 0.f, 0.f);
+// Boxes of the inner nodes, level by level from the leaves' parents to the
+// root, by one block (a level is at most nl / 2 nodes of a few thousand).
+__global__ void __launch_bounds__(1024) k_inner_boxes(float4* node_box, int depth) {
+    for (int level = depth - 1; level >= 0; --level) {
+        const int count = 1 << level;
+        for (int j = threadIdx.x; j < count; j += blockDim.x) {
+            const int64_t node = count + j;
+            float4 a0 = node_box[4 * node], a1 = node_box[4 * node + 1];
+            float4 b0 = node_box[4 * node + 2], b1 = node_box[4 * node + 3];
+            node_box[2 * node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
+            node_box[2 * node + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), 0.f, 0.f);
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------- queries
@@ -626,41 +632,18 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
     if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
 }
 
-// Position of a query along a 3-D Hilbert curve through the photon bounds
-// (10 bits per axis, Skilling's transpose form).  Unlike a Morton curve a
-// Hilbert curve has no jumps: consecutive queries in this order are always
-// neighbours in space, so the search boxes of the 64 queries of a wave overlap.
-TKD uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
-    uint32_t X[3] = {x, y, z};
-    const uint32_t M = 1u << 9;
-    for (uint32_t Q = M; Q > 1; Q >>= 1) {
-        uint32_t P = Q - 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (X[i] & Q) X[0] ^= P;
-            else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
-        }
-    }
-    X[1] ^= X[0];
-    X[2] ^= X[1];
-    uint32_t t = 0;
-    for (uint32_t Q = M; Q > 1; Q >>= 1)
-        if (X[2] & Q) t ^= Q - 1;
-    X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    uint32_t key = 0;
-#pragma unroll
-    for (int b = 9; b >= 0; --b) {
-        key = (key << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
-    }
-    return key;
-}
-__global__ void k_query_curve(QueryView qv, int64_t nq, F3 bmin, F3 binv, uint32_t* keys, uint32_t* vals) {
+// Hilbert key of every query inside the root box of the tree.  Consecutive
+// queries in this order are neighbours in space (a Hilbert curve has no jumps,
+// unlike a Morton curve), so the search boxes of the 64 queries of a wave overlap.
+__global__ void k_query_curve(QueryView qv, int64_t nq, const float4* root_box, uint32_t* keys, uint32_t* vals) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nq) return;
+    const float4 b0 = root_box[0], b1 = root_box[1];
+    const float ex = b0.w - b0.x, ey = b1.x - b0.y, ez = b1.y - b0.z;
     float4 a = qv.q0[i];
-    float fx = fminf(fmaxf((a.x - bmin.x) * binv.x, 0.f), 1023.f);
-    float fy = fminf(fmaxf((a.y - bmin.y) * binv.y, 0.f), 1023.f);
-    float fz = fminf(fmaxf((a.z - bmin.z) * binv.z, 0.f), 1023.f);
+    float fx = fminf(fmaxf((a.x - b0.x) * (ex > 0 ? 1023.f / ex : 0.f), 0.f), 1023.f);
+    float fy = fminf(fmaxf((a.y - b0.y) * (ey > 0 ? 1023.f / ey : 0.f), 0.f), 1023.f);
+    float fz = fminf(fmaxf((a.z - b0.z) * (ez > 0 ? 1023.f / ez : 0.f), 0.f), 1023.f);
     keys[i] = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz);
     vals[i] = (uint32_t)i;
 }
@@ -689,8 +672,7 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
 
 void map_destroy(tkhip_map* m) {
     if (!m) return;
-    DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->node_axis,
-                      &m->clip_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
+    DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
                       &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters, &m->prim_temp};
     for (DevBuf* b : bufs) b->release();
     delete m;
@@ -714,7 +696,14 @@ int map_build(tkhip_map* m) {
     hipStream_t s = m->stream;
     const int64_t n = m->n;
     m->built = false;
-    if (n == 0) { m->nl = 0; m->depth = 0; m->built = true; return TKHIP_OK; }
+    if (n == 0) {
+        // an empty map still answers gathers (nothing found): give it a degenerate root box
+        m->nl = 0; m->depth = 0;
+        TK_TRY(m->node_box.ensure(4 * 16));
+        TK_HIP(hipMemsetAsync(m->node_box.p, 0, 4 * 16, s));
+        m->built = true;
+        return TKHIP_OK;
+    }
     int64_t want = (n + kLeafCap - 1) / kLeafCap;
     int nl = 1, depth = 0;
     while (nl < want) { nl <<= 1; ++depth; }
@@ -723,51 +712,25 @@ int map_build(tkhip_map* m) {
     TK_TRY(m->pos4.ensure((size_t)n * 16));
     TK_TRY(m->pow4.ensure((size_t)n * 16));
     TK_TRY(m->node_box.ensure((size_t)nl * 2 * 32));
-    TK_TRY(m->node_axis.ensure((size_t)nl * 2 * 4));
-    TK_TRY(m->clip_box.ensure((size_t)nl * 2 * 24));
     TK_TRY(m->idx_a.ensure((size_t)n * 4));
     TK_TRY(m->idx_b.ensure((size_t)n * 4));
-    TK_TRY(m->key_a.ensure((size_t)n * 8));
-    TK_TRY(m->key_b.ensure((size_t)n * 8));
+    TK_TRY(m->key_a.ensure((size_t)n * 4));
+    TK_TRY(m->key_b.ensure((size_t)n * 4));
     TK_TRY(m->root_box.ensure(64));
     const float* pos = m->in_pos.as<float>();
-    uint32_t* idx = m->idx_a.as<uint32_t>();
-    uint32_t* idx_alt = m->idx_b.as<uint32_t>();
     const int B = 256;
-    k_iota<<<divup(n, B), B, 0, s>>>(idx, n);
+    uint32_t* box6 = m->root_box.as<uint32_t>();
+    k_bounds_init<<<1, 64, 0, s>>>(box6);
+    k_bounds<<<std::min(divup(n, B * 8), 256), B, 0, s>>>(pos, n, box6);
+    k_photon_curve<<<divup(n, B), B, 0, s>>>(pos, n, box6, m->key_a.as<uint32_t>(), m->idx_b.as<uint32_t>());
     TK_LAUNCH_CHECK();
-    if (depth > 0) {
-        k_root_box_init<<<1, 64, 0, s>>>(m->root_box.as<uint32_t>());
-        k_root_box<<<std::min(divup(n, B), 1024), B, 0, s>>>(pos, n, m->root_box.as<uint32_t>());
-        k_root_finish<<<1, 64, 0, s>>>(m->root_box.as<uint32_t>(), m->clip_box.as<float>());
-        TK_LAUNCH_CHECK();
-        for (int level = 0; level < depth; ++level) {
-            const int nodes = 1 << level;
-            k_level_axis<<<divup(nodes, B), B, 0, s>>>(m->clip_box.as<float>(), m->node_axis.as<int32_t>(), level);
-            k_level_keys<<<divup(n, B), B, 0, s>>>(pos, idx, m->node_axis.as<int32_t>(), m->key_a.as<uint64_t>(), n, nl,
-                                                   depth, level);
-            TK_LAUNCH_CHECK();
-            TK_TRY(sort_pairs_u64(s, m->prim_temp, m->key_a.as<uint64_t>(), m->key_b.as<uint64_t>(), idx, idx_alt, (size_t)n,
-                                  32 + level));
-            std::swap(idx, idx_alt);
-            k_level_split<<<divup(nodes, B), B, 0, s>>>(pos, idx, m->clip_box.as<float>(), m->node_axis.as<int32_t>(), n,
-                                                        nl, depth, level);
-            TK_LAUNCH_CHECK();
-        }
-    }
-    k_permute<<<divup(n, B), B, 0, s>>>(pos, m->in_pow.as<float>(), m->in_dir.as<uint16_t>(), idx, m->pos4.as<float4>(),
-                                        m->pow4.as<float4>(), n);
-    k_leaf_boxes<<<divup(nl, B), B, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl);
-    for (int level = depth - 1; level >= 0; --level)
-        k_inner_boxes<<<divup(1 << level, B), B, 0, s>>>(m->node_box.as<float4>(), level);
+    TK_TRY(sort_pairs_u32(s, m->prim_temp, m->key_a.as<uint32_t>(), m->key_b.as<uint32_t>(), m->idx_b.as<uint32_t>(),
+                          m->idx_a.as<uint32_t>(), (size_t)n, 30));   // idx_a: the leaf order
+    k_permute<<<divup(n, B), B, 0, s>>>(pos, m->in_pow.as<float>(), m->in_dir.as<uint16_t>(), m->idx_a.as<uint32_t>(),
+                                        m->pos4.as<float4>(), m->pow4.as<float4>(), n);
+    k_leaf_boxes<<<divup(nl, 64), 64, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl);
+    if (depth > 0) k_inner_boxes<<<1, 1024, 0, s>>>(m->node_box.as<float4>(), depth);
     TK_LAUNCH_CHECK();
-    if (idx != m->idx_a.as<uint32_t>()) std::swap(m->idx_a, m->idx_b);   // idx_a always holds the final order
-    // the root box orders the queries of later gathers along a space-filling curve
-    float4 rb[2];
-    TK_HIP(hipMemcpyAsync(rb, m->node_box.as<float4>() + 2, sizeof(rb), hipMemcpyDeviceToHost, s));
-    TK_HIP(hipStreamSynchronize(s));
-    m->scene_min[0] = rb[0].x; m->scene_min[1] = rb[0].y; m->scene_min[2] = rb[0].z;
-    m->scene_max[0] = rb[0].w; m->scene_max[1] = rb[1].x; m->scene_max[2] = rb[1].y;
     m->built = true;
     return TKHIP_OK;
 }
@@ -819,12 +782,9 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     TK_TRY(m->q_vals_a.ensure((size_t)nq * 4));
     TK_TRY(m->q_order.ensure((size_t)nq * 4));
     TK_TRY(m->overflow.ensure((size_t)nq * 4));
-    // Hilbert order inside the root box of the tree
-    F3 bmin{m->scene_min[0], m->scene_min[1], m->scene_min[2]};
-    float ex = m->scene_max[0] - m->scene_min[0], ey = m->scene_max[1] - m->scene_min[1],
-          ez = m->scene_max[2] - m->scene_min[2];
-    F3 binv{ex > 0 ? 1023.f / ex : 0.f, ey > 0 ? 1023.f / ey : 0.f, ez > 0 ? 1023.f / ez : 0.f};
-    k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, bmin, binv, m->q_keys_a.as<uint32_t>(), m->q_vals_a.as<uint32_t>());
+    // Hilbert order inside the root box of the tree (heap node 1)
+    k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, m->q_keys_a.as<uint32_t>(),
+                                                 m->q_vals_a.as<uint32_t>());
     TK_LAUNCH_CHECK();
     TK_TRY(sort_pairs_u32(s, m->prim_temp, m->q_keys_a.as<uint32_t>(), m->q_keys_b.as<uint32_t>(), m->q_vals_a.as<uint32_t>(),
                           m->q_order.as<uint32_t>(), (size_t)nq, 30));
