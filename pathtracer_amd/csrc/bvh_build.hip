@@ -142,7 +142,6 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
                int max_stack_depth, HostBvh* out) {
     out->nodes.clear();
     out->order.clear();
-    out->root_leaf = 0x7fffffff;
     out->max_depth = 0;
     for (int a = 0; a < 3; ++a) { out->bmin[a] = 0; out->bmax[a] = 0; }
     int n = n_tris + n_spheres;
@@ -185,7 +184,16 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
     const TmpNode& root = bld.nodes[0];
     for (int a = 0; a < 3; ++a) { out->bmin[a] = root.b.mn[a]; out->bmax[a] = root.b.mx[a]; }
     if (root.left < 0) {
-        out->root_leaf = ~encode_leaf(root);
+        // The whole scene fits one leaf: give the traversal a root node all the same.  Its left
+        // child is that leaf; the right child repeats it behind a box no ray reaches.
+        BvhNode o{};
+        for (int a = 0; a < 3; ++a) {
+            o.lmin[a] = root.b.mn[a]; o.lmax[a] = root.b.mx[a];
+            o.rmin[a] = 3.0e38f; o.rmax[a] = 3.0e38f;
+        }
+        o.left = o.right = encode_leaf(root);
+        o.pad0 = o.pad1 = 0;
+        out->nodes.push_back(o);
         return;
     }
     // number the interior nodes in depth-first order

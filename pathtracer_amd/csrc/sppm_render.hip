@@ -151,7 +151,7 @@ TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
 template <int KIND, class STACK>
 TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, STACK stk) {
     const DScene& sc = a.sc;
-    Hit h = trace_ray<false>(sc, P.o, P.d, 1.7976931348623157e308, stk);
+    Hit h = trace_ray(sc, P.o, P.d, 1.7976931348623157e308, false, stk);
     if (h.prim < 0) return false;
     SurfacePoint sp = surface_at(sc, h, P.o, P.d);
     F3 wo = neg3(P.d);
@@ -208,7 +208,7 @@ TKD int wave_fetch_work(int32_t* cursor, bool idle, int64_t n, bool* exhausted) 
 // with its wave, and a lane whose path has ended takes the next unstarted path
 // of the batch, so that waves stay full until the batch runs out.
 template <int KIND>
-__global__ void __launch_bounds__(kPathBlock) k_photon_paths(PhotonArgs a, int64_t B, int32_t* counters) {
+__global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, int64_t B, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     bool alive = false, exhausted = false;
@@ -331,7 +331,7 @@ TKD bool camera_step(const CameraArgs& a, int x, int y, int pixel, int bounce, C
     out.nrays = 1;
     bool has_glossy = P.flags & 1;
     Sampler sm = make_sampler(a, x, y, P.flags >> 1);
-    Hit h = trace_ray<false>(sc, P.o, P.d, 1.7976931348623157e308, stk);
+    Hit h = trace_ray(sc, P.o, P.d, 1.7976931348623157e308, false, stk);
     if (h.prim < 0) return false;
     const SurfacePoint sp = surface_at(sc, h, P.o, P.d);
     const TkMaterial m = sc.mats[sp.mat];
@@ -366,7 +366,7 @@ TKD bool camera_step(const CameraArgs& a, int x, int y, int pixel, int bounce, C
                     // Intersection::spawnRayTo(other), src/Intersection.hpp:40-48
                     F3 so2 = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
                     F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(so2, lp.p));
-                    Hit sh = trace_ray<true>(sc, so2, sub3(target, so2), (double)kOneMinusEps, stk);
+                    Hit sh = trace_ray(sc, so2, sub3(target, so2), (double)kOneMinusEps, true, stk);
                     ++out.nrays;
                     if (sh.prim < 0) {
                         F3 f = mat_f(m, sp.wo, ws, sp.n);
@@ -414,7 +414,7 @@ TKD void count_rays(int32_t* counters, int nrays) {
 
 // The camera pass of this rank's pixels, organised like k_photon_paths: lanes
 // that finish a path start the next unstarted pixel.
-__global__ void __launch_bounds__(kPathBlock) k_camera_paths(CameraArgs a, int64_t n_slots, int32_t* counters) {
+__global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int64_t n_slots, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     bool alive = false, exhausted = false;

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_trace_rays(DScene sc, int64_t n, const 
     if (i >= n) return;
     F3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
     double tm = tmax ? (double)tmax[i] : 1.7976931348623157e308;
-    Hit h = trace_ray<false>(sc, o, d, tm, stk);
+    Hit h = trace_ray(sc, o, d, tm, false, stk);
     prim[i] = h.prim;
     SurfacePoint sp{};
     if (h.prim >= 0) sp = surface_at(sc, h, o, d);
@@ -243,7 +243,6 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     sc.light_cdf = ctx->b_cdf.as<float>();
     sc.n_tris = n_tris; sc.n_spheres = n_spheres; sc.n_lights = n_lights;
     sc.n_nodes = (int32_t)bvh.nodes.size();
-    sc.root_leaf = bvh.root_leaf;
     for (int a = 0; a < 3; ++a) { sc.bmin[a] = bvh.bmin[a]; sc.bmax[a] = bvh.bmax[a]; }
     ctx->has_scene = true;
     return TKHIP_OK;

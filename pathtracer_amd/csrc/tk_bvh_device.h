@@ -85,7 +85,10 @@ TKD bool ef_quadratic(EF a, EF b, EF c, EF* t0, EF* t1) {      // src/EFloat.h:1
     return true;
 }
 
-// Sphere::intersect up to the choice of the root (src/Sphere.cpp:14-37).
+// Sphere::intersect up to the choice of the root (src/Sphere.cpp:14-37).  Kept
+// out of line: scenes hold a handful of spheres at most, and the interval
+// arithmetic is several hundred instructions that would otherwise be repeated
+// inside every traversal loop.
 TKD bool sphere_hit_t(float4 sph, F3 o, F3 d, double tmax, float* thit) {
     EF ox = ef_sub(ef_make(o.x), ef_make(sph.x));
     EF oy = ef_sub(ef_make(o.y), ef_make(sph.y));
@@ -165,23 +168,24 @@ TKD void prim_test(const DScene& sc, const TriIsect& T, F3 o, F3 d, Hit* h) {
     }
 }
 
-// A leaf holds at most kMaxLeaf primitives; their records are fetched together
-// (independent loads in flight) before any of them is tested.
-template <bool ANY_HIT>
-TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int64_t* nprims) {
-    int first = enc >> 3, count = (enc & 7) + 1;
+// A leaf holds at most kMaxLeaf primitives; the records of the first two are
+// fetched together (independent loads in flight) before either is tested.
+TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h) {
+    const int first = enc >> 3, count = (enc & 7) + 1;
     const TriIsect T0 = sc.tri_isect[first];
     const TriIsect T1 = sc.tri_isect[first + (count > 1 ? 1 : 0)];
     prim_test(sc, T0, o, d, h);
     if (count > 1) prim_test(sc, T1, o, d, h);
-    for (int i = 2; i < count; ++i) {
-        const TriIsect T = sc.tri_isect[first + i];
-        prim_test(sc, T, o, d, h);
+    if (kMaxLeaf > 2) {
+        for (int i = 2; i < count; ++i) {
+            const TriIsect T = sc.tri_isect[first + i];
+            prim_test(sc, T, o, d, h);
+        }
     }
 }
 
-// Closest hit (ANY_HIT = false) or occlusion (ANY_HIT = true: stops at the
-// first hit below tmax, enough for the boolean Scene::intersectP answers,
+// Closest hit, or occlusion when any_hit is set (stops at the first hit below
+// tmax, enough for the boolean Scene::intersectP answers,
 // src/core/Scene.cpp:27-31).
 //
 // Two nested loops: the inner one only walks inner nodes (two slab tests and a
@@ -189,16 +193,15 @@ TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int64_t* nprim
 // leaf then run once the whole wave is out of the inner loop, with most lanes
 // taking part, instead of a few lanes at a time in the middle of the descent.
 // Stack entries are inner nodes (>= 0) or leaves (< 0, ~encoding).
-template <bool ANY_HIT, class STACK>
-TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, STACK st) {
+template <class STACK>
+TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK st) {
     Hit h;
     h.prim = -1; h.t = tmax; h.u = 0; h.v = 0;
-    if (sc.n_nodes == 0) {
-        if (sc.root_leaf != 0x7fffffff) leaf_test<ANY_HIT>(sc, sc.root_leaf, o, d, &h, nullptr);
-        return h;
-    }
-    // Ray ctor: direction_inv = float(1.0 / double(dir)) (src/Ray.hpp:21)
-    const F3 dinv = mk3((float)(1. / (double)d.x), (float)(1. / (double)d.y), (float)(1. / (double)d.z));
+    if (sc.n_nodes == 0) return h;
+    // Ray ctor: direction_inv = float(1.0 / double(dir)) (src/Ray.hpp:21).  The correctly rounded
+    // fp32 quotient is the same number: 1/x for a 24-bit x never lies within a double's rounding
+    // error of a midpoint between two floats.
+    const F3 dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     constexpr int kDone = 0x7fffffff;
     int sp = 0;
     int cur = 0;
@@ -226,11 +229,10 @@ TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, STACK st) {
             }
         }
         if (cur == kDone) break;
-        leaf_test<ANY_HIT>(sc, ~cur, o, d, &h, nullptr);
-        if (ANY_HIT && h.prim >= 0) return h;
+        leaf_test(sc, ~cur, o, d, &h);
         tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
-        if (sp > 0) { --sp; cur = st.pop(sp); }
-        else cur = kDone;
+        if ((any_hit && h.prim >= 0) || sp == 0) cur = kDone;
+        else { --sp; cur = st.pop(sp); }
     }
     return h;
 }

@@ -119,7 +119,6 @@ struct DScene {
     const DLight* lights;
     const float* light_cdf;
     int32_t n_tris, n_spheres, n_lights, n_nodes;
-    int32_t root_leaf;              // >= 0: the whole scene is one leaf (encoded as child)
     float bmin[3], bmax[3];
 };
 
@@ -132,7 +131,6 @@ struct DCamera {
 struct HostBvh {
     std::vector<BvhNode> nodes;
     std::vector<int32_t> order;     // slot -> original primitive id
-    int32_t root_leaf = 0;
     int max_depth = 0;
     float bmin[3], bmax[3];
 };
