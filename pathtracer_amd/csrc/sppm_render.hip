@@ -287,12 +287,23 @@ TKD Sampler make_sampler(const CameraArgs& a, int x, int y, int dim) {
     return s;
 }
 
-// The camera sample of slot `slot` of this rank's pixel rows
-// (src/tracer/TkSppmTracer.cpp:296-304).
+// State of one camera path between two rays.  A lane traces one ray per turn
+// of the kernel's loop: the path's next segment, or the shadow ray of the
+// light sample taken at the last diffuse hit.  While the shadow ray is out,
+// everything the hit already decided waits in the `next_*` / `ld_*` fields.
 struct CameraPath {
-    F3 o, d, coef;
+    F3 o, d;       // the ray to trace now
+    F3 coef;       // throughput of the path up to the ray's origin
     int flags;     // bit0: only specular surfaces so far; bits 1..: sampler dimension
+    bool shadow;   // the ray is a shadow ray
+    F3 ld_seen;    // emitted radiance seen at the hit the shadow ray left from
+    F3 ld_light;   // light sample's contribution, added if the shadow ray arrives
+    F3 next_o, next_d, next_coef;
+    int next_flags;
+    bool next_alive;
 };
+
+// The camera sample of a pixel (src/tracer/TkSppmTracer.cpp:296-304).
 TKD void camera_start(const CameraArgs& a, int x, int y, CameraPath& P) {
     Sampler sm = make_sampler(a, x, y, 0);
     float cx, cy, lx, ly;
@@ -302,6 +313,7 @@ TKD void camera_start(const CameraArgs& a, int x, int y, CameraPath& P) {
     camera_ray(a.cam, cx, cy, &P.o, &P.d);
     P.coef = mk3(1.f, 1.f, 1.f);
     P.flags = 1 | (sm.dim << 1);
+    P.shadow = false;
 }
 
 TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp, F3 coef, const TkMaterial& m,
@@ -312,27 +324,30 @@ TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp
     qbase[3 * qcap + dst] = make_float4(m.R[0] * kInvPi, m.R[1] * kInvPi, m.R[2] * kInvPi, 0.f);
 }
 
-// One bounce of a camera path (loop body of traceTile,
+TKD void add_direct(const CameraArgs& a, int pixel, F3 Ld) {
+    if (!isblack(Ld)) {
+        a.planes[pixel] += Ld.x;
+        a.planes[a.n_pixels + pixel] += Ld.y;
+        a.planes[2 * a.n_pixels + pixel] += Ld.z;
+    }
+}
+
+// What a hit of a path segment leads to (loop body of traceTile,
 // src/tracer/TkSppmTracer.cpp:306-371, with Scene::uniformSampleOneLight,
 // src/core/Scene.cpp:43-61, inlined).  Gather queries are reported through
-// want_cq / want_gq together with the surface they belong to.
+// want_cq / want_gq together with the surface they belong to.  Returns true
+// while the lane has another ray to trace (P.o, P.d, P.shadow).
 struct CameraStepOut {
     bool want_cq, want_gq;
     SurfacePoint sp;
     F3 coef;
     TkMaterial m;
-    int nrays;
 };
-template <class STACK>
-TKD bool camera_step(const CameraArgs& a, int x, int y, int pixel, int bounce, CameraPath& P, CameraStepOut& out,
-                     STACK stk) {
+TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce, const Hit& h, CameraPath& P,
+                       CameraStepOut& out) {
     const DScene& sc = a.sc;
-    out.want_cq = out.want_gq = false;
-    out.nrays = 1;
     bool has_glossy = P.flags & 1;
     Sampler sm = make_sampler(a, x, y, P.flags >> 1);
-    Hit h = trace_ray(sc, P.o, P.d, 1.7976931348623157e308, false, stk);
-    if (h.prim < 0) return false;
     const SurfacePoint sp = surface_at(sc, h, P.o, P.d);
     const TkMaterial m = sc.mats[sp.mat];
     const bool diffuse = m.type == TK_DIFFUSE;
@@ -340,6 +355,8 @@ TKD bool camera_step(const CameraArgs& a, int x, int y, int pixel, int bounce, C
     const F3 coef = P.coef;
     F3 Ld = mk3(0, 0, 0);
     if (has_glossy && sp.light >= 0) Ld = add3(Ld, mul3(coef, light_L(sc.lights[sp.light], sp.n, wo)));
+    bool want_shadow = false;
+    F3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 0), ld_light = mk3(0, 0, 0);
     if ((has_glossy || !diffuse) && sc.n_lights > 0) {
         // uniformSampleOneLight: the sampler dimensions advance for every material
         int nl = sc.n_lights;
@@ -364,40 +381,49 @@ TKD bool camera_step(const CameraArgs& a, int x, int y, int pixel, int bounce, C
                 F3 Li = light_L(L, lp.n, neg3(ws));
                 if (!isblack(Li)) {
                     // Intersection::spawnRayTo(other), src/Intersection.hpp:40-48
-                    F3 so2 = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
-                    F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(so2, lp.p));
-                    Hit sh = trace_ray(sc, so2, sub3(target, so2), (double)kOneMinusEps, true, stk);
-                    ++out.nrays;
-                    if (sh.prim < 0) {
-                        F3 f = mat_f(m, sp.wo, ws, sp.n);
-                        Ld = add3(Ld, mul3(coef, divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice)));
-                    }
+                    sh_o = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
+                    F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(sh_o, lp.p));
+                    sh_d = sub3(target, sh_o);
+                    F3 f = mat_f(m, sp.wo, ws, sp.n);
+                    ld_light = mul3(coef, divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice));
+                    want_shadow = true;
                 }
             }
         }
     }
-    if (!isblack(Ld)) {
-        a.planes[pixel] += Ld.x;
-        a.planes[a.n_pixels + pixel] += Ld.y;
-        a.planes[2 * a.n_pixels + pixel] += Ld.z;
-    }
+    // what follows the light sample does not depend on the shadow ray's answer
+    bool go_on = true;
     if (diffuse) {
         out.sp = sp; out.coef = coef; out.m = m;
         if (has_glossy && a.caustic_stored > 0) out.want_cq = true;
-        if (!has_glossy) { out.want_gq = true; return false; }
+        if (!has_glossy) { out.want_gq = true; go_on = false; }
     }
-    has_glossy = has_glossy && !diffuse;
-    float ux, uy;
-    sampler_get2d(sm, &ux, &uy);
-    F3 wi;
-    float pdf;
-    F3 f = mat_sample_f(m, false, wo, &wi, sp.n, ux, uy, &pdf);
-    if (isblack(f) || pdf == 0 || !(bounce + 1 < a.depth)) return false;
-    P.coef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
-    P.o = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
-    P.d = wi;
-    P.flags = (has_glossy ? 1 : 0) | (sm.dim << 1);
-    return true;
+    F3 n_o = P.o, n_d = P.d, n_coef = coef;
+    int n_flags = P.flags;
+    if (go_on) {
+        has_glossy = has_glossy && !diffuse;
+        float ux, uy;
+        sampler_get2d(sm, &ux, &uy);
+        F3 wi;
+        float pdf;
+        F3 f = mat_sample_f(m, false, wo, &wi, sp.n, ux, uy, &pdf);
+        if (isblack(f) || pdf == 0 || !(bounce + 1 < a.depth)) go_on = false;
+        else {
+            n_coef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
+            n_o = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
+            n_d = wi;
+            n_flags = (has_glossy ? 1 : 0) | (sm.dim << 1);
+        }
+    }
+    if (want_shadow) {
+        P.ld_seen = Ld; P.ld_light = ld_light;
+        P.next_o = n_o; P.next_d = n_d; P.next_coef = n_coef; P.next_flags = n_flags; P.next_alive = go_on;
+        P.o = sh_o; P.d = sh_d; P.shadow = true;
+        return true;
+    }
+    add_direct(a, pixel, Ld);
+    P.o = n_o; P.d = n_d; P.coef = n_coef; P.flags = n_flags;
+    return go_on;
 }
 TKD void camera_emit_queries(const CameraArgs& a, int32_t* counters, const CameraStepOut& o, int pixel) {
     int dc = wave_append(&counters[C_NCQ], o.want_cq);
@@ -413,7 +439,8 @@ TKD void count_rays(int32_t* counters, int nrays) {
 }
 
 // The camera pass of this rank's pixels, organised like k_photon_paths: lanes
-// that finish a path start the next unstarted pixel.
+// that finish a path start the next unstarted pixel, and every turn of the
+// loop traces one ray per lane, path segments and shadow rays side by side.
 __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int64_t n_slots, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
@@ -437,10 +464,24 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
             continue;
         }
         CameraStepOut so{};
+        so.want_cq = so.want_gq = false;
         if (alive) {
-            alive = camera_step(a, x, y, pixel, bounce, P, so, stk);
-            nrays += so.nrays;
-            ++bounce;
+            ++nrays;
+            const Hit h = trace_ray(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+            if (P.shadow) {
+                F3 Ld = P.ld_seen;
+                if (h.prim < 0) Ld = add3(Ld, P.ld_light);
+                add_direct(a, pixel, Ld);
+                P.o = P.next_o; P.d = P.next_d; P.coef = P.next_coef; P.flags = P.next_flags;
+                P.shadow = false;
+                alive = P.next_alive;
+                ++bounce;
+            } else if (h.prim < 0) {
+                alive = false;
+            } else {
+                alive = camera_on_hit(a, x, y, pixel, bounce, h, P, so);
+                if (!P.shadow) ++bounce;
+            }
         }
         camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
     }
