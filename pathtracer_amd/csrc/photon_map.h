@@ -65,6 +65,8 @@ int map_build(tkhip_map* m);
 // nq queries on the device -> out.  mode 0: grouped kernel then per-query
 // kernel for the overflow; mode 1: per-query kernel only.  timed: record the
 // grouped kernel's duration with events (synchronises).
+// Sizes the scratch of gathers of up to nq queries (so that later gathers do not reallocate).
+int map_reserve_queries(tkhip_map* m, int64_t nq);
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed);
 
 }  // namespace tkd

@@ -759,6 +759,16 @@ static void launch_wave(tkhip_map* m, const QueryView& qv, const int32_t* list, 
     k_gather_wave<EPL><<<blocks, 256, 0, m->stream>>>(m->view(), qv, list, list_count, nq, out);
 }
 
+int map_reserve_queries(tkhip_map* m, int64_t nq) {
+    TK_TRY(m->q_keys_a.ensure((size_t)nq * 4));
+    TK_TRY(m->q_keys_b.ensure((size_t)nq * 4));
+    TK_TRY(m->q_vals_a.ensure((size_t)nq * 4));
+    TK_TRY(m->q_order.ensure((size_t)nq * 4));
+    TK_TRY(m->overflow.ensure((size_t)nq * 4));
+    TK_TRY(sort_pairs_u32_reserve(m->prim_temp, (size_t)nq, 30));
+    return TKHIP_OK;
+}
+
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed) {
     TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
     if (nq == 0) return TKHIP_OK;
@@ -777,11 +787,7 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         TK_LAUNCH_CHECK();
         return TKHIP_OK;
     }
-    TK_TRY(m->q_keys_a.ensure((size_t)nq * 4));
-    TK_TRY(m->q_keys_b.ensure((size_t)nq * 4));
-    TK_TRY(m->q_vals_a.ensure((size_t)nq * 4));
-    TK_TRY(m->q_order.ensure((size_t)nq * 4));
-    TK_TRY(m->overflow.ensure((size_t)nq * 4));
+    TK_TRY(map_reserve_queries(m, nq));
     // Hilbert order inside the root box of the tree (heap node 1)
     k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, m->q_keys_a.as<uint32_t>(),
                                                  m->q_vals_a.as<uint32_t>());

@@ -1,13 +1,15 @@
 // sppm_render.hip — one SPPM iteration on the device: photon passes, map
 // builds, camera pass with gathers, resolve.
 //
-// Shape of the work: a pass is one launch of a path kernel whose grid fills
-// the GPU once; each lane walks a whole path, bounce by bounce, and takes the
-// next unstarted path when its own ends (the LDS-stack traversal of
-// tk_bvh_device.h traces the rays):
-//   photon pass : k_photon_paths<KIND> -> scan -> k_photon_scatter
+// Shape of the work: a pass has two stages.  The first traces the first
+// segment of every path, one path per lane in plain full waves (these rays are
+// alike and cheap); paths that go on are queued.  The second is one launch
+// whose grid fills the GPU once: each lane walks a queued path to its end,
+// bounce by bounce, and takes the next queued path when its own ends (the
+// LDS-stack traversal of tk_bvh_device.h traces the rays):
+//   photon pass : k_photon_first<KIND> -> k_photon_paths<KIND> -> scan -> k_photon_scatter
 //                 (tracePhoton / traceCausticPhoton, src/tracer/TkSppmTracer.cpp:104-217)
-//   camera pass : k_camera_paths -> gathers
+//   camera pass : k_camera_first -> k_camera_paths -> gathers
 //                 (traceTile, src/tracer/TkSppmTracer.cpp:290-374)
 //   resolve     : k_resolve (src/tracer/TkSppmTracer.cpp:514-529)
 //
@@ -30,7 +32,7 @@
 
 namespace tkd {
 
-enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */ };
+enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */, C_QD = 12 };
 
 // Everything one concurrently running pass needs: its stream, path state,
 // queues, counters and scratch.  Lane 0 traces the global photons and builds
@@ -40,10 +42,11 @@ enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 1, C_NGQ = 2, C_NC
 struct Lane {
     hipStream_t stream = nullptr;
     DevBuf counters;
+    DevBuf q_o, q_d, q_w;            // path records between the two stages of a pass
     int32_t* h_counters = nullptr;   // pinned host copy of the first counters
     DevBuf stage_pos, stage_pow, rec_count, rec_offset, prim_temp;
     void release() {
-        DevBuf* bufs[] = {&counters, &stage_pos, &stage_pow, &rec_count, &rec_offset, &prim_temp};
+        DevBuf* bufs[] = {&counters, &q_o, &q_d, &q_w, &stage_pos, &stage_pow, &rec_count, &rec_offset, &prim_temp};
         for (DevBuf* b : bufs) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
@@ -76,8 +79,29 @@ struct SppmState {
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
 };
 
+// Paths that outlive the first stage of a pass wait here for the second one,
+// three float4 per path.  Paths leaving a specular surface are appended from
+// the front (counter C_QB), the others from the back (counter C_QD): the
+// second stage takes the specular ones first.  They are the long and costly
+// paths (chains of reflections inside glass), so they start early and do not
+// share waves with the many paths that need one more ray.
+struct PathQueue {
+    float4* o;
+    float4* d;
+    float4* w;
+    int cap;
+};
+TKD int queue_push(const PathQueue& q, int32_t* counters, bool want, bool specular) {   // wave-wide
+    const int is = wave_append(&counters[C_QB], want && specular);
+    const int id = wave_append(&counters[C_QD], want && !specular);
+    if (!want) return -1;
+    return specular ? is : q.cap - 1 - id;
+}
+TKD int queue_index(const PathQueue& q, int w, int n_front) { return w < n_front ? w : q.cap - 1 - (w - n_front); }
+
 struct PhotonArgs {
     DScene sc;
+    PathQueue q;
     int32_t* rec_count;
     float4* stage_pos;   // xyz + direction bits
     float4* stage_pow;   // rgb
@@ -149,7 +173,7 @@ TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
 // Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156 for the
 // global map, :179-216 for the caustic map).  Returns true while the path lives.
 template <int KIND, class STACK>
-TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, STACK stk) {
+TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, bool* specular, STACK stk) {
     const DScene& sc = a.sc;
     Hit h = trace_ray(sc, P.o, P.d, 1.7976931348623157e308, false, stk);
     if (h.prim < 0) return false;
@@ -157,6 +181,7 @@ TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, S
     F3 wo = neg3(P.d);
     const TkMaterial m = sc.mats[sp.mat];
     bool diffuse = m.type == TK_DIFFUSE;
+    *specular = !diffuse;
     if (KIND == 0) {
         if (diffuse) {
             int c = P.flags;   // photons this path has staged so far
@@ -203,25 +228,70 @@ TKD int wave_fetch_work(int32_t* cursor, bool idle, int64_t n, bool* exhausted) 
     return (idle && mine < n) ? mine : -1;
 }
 
-// The photon pass of one batch of B light paths.  The grid is sized to fill
-// the GPU once; every lane walks one path at a time, bounce by bounce in step
-// with its wave, and a lane whose path has ended takes the next unstarted path
-// of the batch, so that waves stay full until the batch runs out.
+TKD void count_wave_rays(int32_t* counters, int nrays) {
+    float wr = (float)nrays;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
+    if ((threadIdx.x & 63) == 0 && wr > 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
+}
+
+// First stage of the photon pass of a batch of B light paths: emission and the
+// first segment of every path, one path per lane.  These rays all leave the
+// lights, cost about the same and most caustic paths end here (at a diffuse
+// surface), so plain full waves are the efficient shape.  Paths that go on are
+// queued for the second stage.
 template <int KIND>
-__global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, int64_t B, int32_t* counters) {
+__global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int64_t B, int32_t* counters) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool alive = false, specular = false;
+    int traced = 0;
+    PhotonPath P{};
+    if (i < B) {
+        if (KIND == 1) a.rec_count[i] = 0;
+        alive = photon_emit<KIND>(a, (int)i, P);
+        if (alive) {
+            traced = 1;
+            alive = photon_step<KIND>(a, (int)i, 0, P, &specular, stk);
+        }
+        if (KIND == 0 && !alive) a.rec_count[i] = P.flags;
+    }
+    const int at = queue_push(a.q, counters, alive, specular);
+    if (alive) {
+        a.q.o[at] = make_float4(P.o.x, P.o.y, P.o.z, P.ubx);
+        a.q.d[at] = make_float4(P.d.x, P.d.y, P.d.z, P.uby);
+        a.q.w[at] = make_float4(P.power.x, P.power.y, P.power.z, __int_as_float((int)i | (P.flags << 24)));
+    }
+    count_wave_rays(counters, traced);
+}
+
+// Second stage: the queued paths from their second segment on.  The grid is
+// sized to fill the GPU once; every lane walks one path at a time, bounce by
+// bounce in step with its wave, and a lane whose path has ended takes the next
+// queued path, so that waves stay full until the queue runs out.
+template <int KIND>
+__global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
+    const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     bool alive = false, exhausted = false;
     int slot = 0, bounce = 0, traced = 0;
     PhotonPath P{};
     while (true) {
         if (!exhausted && !__all(alive)) {
-            const int got = wave_fetch_work(&counters[C_QA], !alive, B, &exhausted);
+            const int got = wave_fetch_work(&counters[C_QA], !alive, n, &exhausted);
             if (got >= 0) {
-                slot = got; bounce = 0;
-                if (KIND == 1) a.rec_count[slot] = 0;
-                alive = photon_emit<KIND>(a, slot, P);
-                if (KIND == 0 && !alive) a.rec_count[slot] = 0;
+                const int at = queue_index(a.q, got, n_front);
+                const float4 ro = a.q.o[at], rd = a.q.d[at], rw = a.q.w[at];
+                P.o = mk3(ro.x, ro.y, ro.z); P.ubx = ro.w;
+                P.d = mk3(rd.x, rd.y, rd.z); P.uby = rd.w;
+                P.power = mk3(rw.x, rw.y, rw.z);
+                const int packed = __float_as_int(rw.w);
+                slot = packed & 0xffffff;
+                P.flags = packed >> 24;
+                bounce = 1;
+                alive = true;
             }
         }
         if (!__any(alive)) {
@@ -230,15 +300,13 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
         }
         if (alive) {
             ++traced;
-            alive = photon_step<KIND>(a, slot, bounce, P, stk);
+            bool specular;
+            alive = photon_step<KIND>(a, slot, bounce, P, &specular, stk);
             ++bounce;
             if (KIND == 0 && !alive) a.rec_count[slot] = P.flags;
         }
     }
-    float wr = (float)traced;
-    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
-    if ((threadIdx.x & 63) == 0 && wr > 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
+    count_wave_rays(counters, traced);
 }
 
 // Appends the staged photons of the batch in path order behind the `base`
@@ -278,6 +346,7 @@ struct CameraArgs {
     float4* gq;          // global queries: 4 arrays of capacity n_slots, back to back
     float4* cq;          // caustic queries
     int64_t qcap;
+    PathQueue q;
 };
 
 TKD Sampler make_sampler(const CameraArgs& a, int x, int y, int dim) {
@@ -431,31 +500,87 @@ TKD void camera_emit_queries(const CameraArgs& a, int32_t* counters, const Camer
     int dg = wave_append(&counters[C_NGQ], o.want_gq);
     if (o.want_gq) emit_query(a.gq, a.qcap, dg, o.sp, o.coef, o.m, a.planes[12 * a.n_pixels + pixel], pixel);
 }
-TKD void count_rays(int32_t* counters, int nrays) {
-    float wr = (float)nrays;
-    for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
-    if ((threadIdx.x & 63) == 0 && wr > 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
+// One turn of a camera path: traces the lane's ray (a path segment or the
+// pending shadow ray) and takes what follows from it.  Returns true while the
+// lane has another ray to trace.
+template <class STACK>
+TKD bool camera_turn(const CameraArgs& a, int x, int y, int pixel, int& bounce, CameraPath& P, CameraStepOut& so,
+                     STACK stk) {
+    const Hit h = trace_ray(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+    if (P.shadow) {
+        F3 Ld = P.ld_seen;
+        if (h.prim < 0) Ld = add3(Ld, P.ld_light);
+        add_direct(a, pixel, Ld);
+        P.o = P.next_o; P.d = P.next_d; P.coef = P.next_coef; P.flags = P.next_flags;
+        P.shadow = false;
+        ++bounce;
+        return P.next_alive;
+    }
+    if (h.prim < 0) return false;
+    const bool go_on = camera_on_hit(a, x, y, pixel, bounce, h, P, so);
+    if (!P.shadow) ++bounce;
+    return go_on;
 }
 
-// The camera pass of this rank's pixels, organised like k_photon_paths: lanes
-// that finish a path start the next unstarted pixel, and every turn of the
-// loop traces one ray per lane, path segments and shadow rays side by side.
-__global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int64_t n_slots, int32_t* counters) {
+// First stage of the camera pass: the camera ray of every pixel of this rank,
+// what its hit leads to, and the shadow ray of the light sample taken there,
+// one pixel per lane.  Camera rays are coherent and cheap and so are the shadow
+// rays that follow them; paths that go on are queued for the second stage.
+__global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int64_t n_slots, int32_t* counters) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool alive = slot < n_slots;
+    int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
+    CameraPath P{};
+    CameraStepOut so{};
+    so.want_cq = so.want_gq = false;
+    if (alive) {
+        const int W = a.cam.w;
+        y = a.rows[slot / W]; x = (int)(slot % W);
+        pixel = x + y * W;
+        camera_start(a, x, y, P);
+        nrays = 1;
+        alive = camera_turn(a, x, y, pixel, bounce, P, so, stk);
+    }
+    camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
+    if (alive && P.shadow) {
+        ++nrays;
+        CameraStepOut none{};
+        alive = camera_turn(a, x, y, pixel, bounce, P, none, stk);
+    }
+    const int at = queue_push(a.q, counters, alive, (P.flags & 1) != 0);
+    if (alive) {
+        a.q.o[at] = make_float4(P.o.x, P.o.y, P.o.z, __int_as_float(pixel));
+        a.q.d[at] = make_float4(P.d.x, P.d.y, P.d.z, __int_as_float(P.flags));
+        a.q.w[at] = make_float4(P.coef.x, P.coef.y, P.coef.z, __int_as_float(bounce));
+    }
+    count_wave_rays(counters, nrays);
+}
+
+// Second stage: the queued paths from their second segment on, organised like
+// k_photon_paths; every turn of the loop traces one ray per lane, path
+// segments and shadow rays side by side.
+__global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
+    const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     bool alive = false, exhausted = false;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
     CameraPath P{};
     const int W = a.cam.w;
     while (true) {
         if (!exhausted && !__all(alive)) {
-            const int got = wave_fetch_work(&counters[C_QA], !alive, n_slots, &exhausted);
+            const int got = wave_fetch_work(&counters[C_QA], !alive, n, &exhausted);
             if (got >= 0) {
-                y = a.rows[got / W]; x = got % W;
-                pixel = x + y * W;
-                bounce = 0;
-                camera_start(a, x, y, P);
+                const int at = queue_index(a.q, got, n_front);
+                const float4 ro = a.q.o[at], rd = a.q.d[at], rw = a.q.w[at];
+                P.o = mk3(ro.x, ro.y, ro.z); P.d = mk3(rd.x, rd.y, rd.z); P.coef = mk3(rw.x, rw.y, rw.z);
+                pixel = __float_as_int(ro.w);
+                P.flags = __float_as_int(rd.w);
+                bounce = __float_as_int(rw.w);
+                P.shadow = false;
+                y = pixel / W; x = pixel - y * W;
                 alive = true;
             }
         }
@@ -467,25 +592,11 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
         so.want_cq = so.want_gq = false;
         if (alive) {
             ++nrays;
-            const Hit h = trace_ray(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
-            if (P.shadow) {
-                F3 Ld = P.ld_seen;
-                if (h.prim < 0) Ld = add3(Ld, P.ld_light);
-                add_direct(a, pixel, Ld);
-                P.o = P.next_o; P.d = P.next_d; P.coef = P.next_coef; P.flags = P.next_flags;
-                P.shadow = false;
-                alive = P.next_alive;
-                ++bounce;
-            } else if (h.prim < 0) {
-                alive = false;
-            } else {
-                alive = camera_on_hit(a, x, y, pixel, bounce, h, P, so);
-                if (!P.shadow) ++bounce;
-            }
+            alive = camera_turn(a, x, y, pixel, bounce, P, so, stk);
         }
         camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
     }
-    count_rays(counters, nrays);
+    count_wave_rays(counters, nrays);
 }
 
 // Final colour + gamma + RGB8, rows bottom-up (src/tracer/TkSppmTracer.cpp:514-529)
@@ -576,6 +687,10 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     TK_TRY(ln.rec_offset.ensure((size_t)B * 4));
     PhotonArgs a;
     a.sc = ctx->scene;
+    TK_TRY(ln.q_o.ensure((size_t)B * 16));
+    TK_TRY(ln.q_d.ensure((size_t)B * 16));
+    TK_TRY(ln.q_w.ensure((size_t)B * 16));
+    a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)B};
     a.rec_count = ln.rec_count.as<int32_t>();
     a.stage_pos = ln.stage_pos.as<float4>();
     a.stage_pow = ln.stage_pow.as<float4>();
@@ -585,8 +700,10 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     a.hoff = KIND == 0 ? 0 : s->caustic_hoff;
     a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
     TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
+    TK_HIP(hipMemsetAsync(&counters[C_QD], 0, 4, stream));
+    k_photon_first<KIND><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
     const int waves = (int)std::min<int64_t>(divup(B, kPathBlock), s->path_waves[KIND]);
-    k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, B, counters);
+    k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
     k_photon_scatter<<<divup(B, 256), 256, 0, stream>>>(ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(),
@@ -682,10 +799,13 @@ static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.gq = s->qbuf[0].as<float4>();
     a.cq = s->qbuf[1].as<float4>();
     a.qcap = s->n_slots;
+    a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)s->n_slots};
     TK_HIP(hipMemsetAsync(counters, 0, 4 * 4, stream));
     TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
+    TK_HIP(hipMemsetAsync(&counters[C_QD], 0, 4, stream));
+    k_camera_first<<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
     const int waves = (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
-    k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, s->n_slots, counters);
+    k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
     TK_HIP(hipStreamSynchronize(stream));
@@ -886,6 +1006,8 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     if (!rc) rc = s->planes.ensure((size_t)s->n_pixels * 13 * 4);
     if (!rc) rc = s->rows.ensure(std::max<size_t>(rows.size(), 1) * 4);
     for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
+    for (DevBuf* b : {&s->lane[2].q_o, &s->lane[2].q_d, &s->lane[2].q_w})
+        if (!rc) rc = b->ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 16);
     if (rc) { destroy_sppm(ctx); return rc; }
     if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     k_init_planes<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, param->radius2);

@@ -165,6 +165,8 @@ int sort_pairs_u64(hipStream_t stream, DevBuf& temp, uint64_t* kin, uint64_t* ko
                    size_t n, int end_bit);
 int sort_pairs_u32(hipStream_t stream, DevBuf& temp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout,
                    size_t n, int end_bit);
+// Grows `temp` to what sort_pairs_u32 of n pairs needs, without sorting.
+int sort_pairs_u32_reserve(DevBuf& temp, size_t n, int end_bit);
 int exclusive_scan_i32(hipStream_t stream, DevBuf& temp, const int32_t* in, int32_t* out, size_t n);
 
 int upload_direction_tables(tkhip_ctx* ctx);

@@ -28,6 +28,14 @@ int sort_pairs_u32(hipStream_t stream, DevBuf& temp, uint32_t* kin, uint32_t* ko
     return sort_pairs_impl<uint32_t>(stream, temp, kin, kout, vin, vout, n, end_bit);
 }
 
+int sort_pairs_u32_reserve(DevBuf& temp, size_t n, int end_bit) {
+    if (n == 0) return TKHIP_OK;
+    size_t bytes = 0;
+    uint32_t* none = nullptr;
+    TK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, none, none, none, none, n, 0, end_bit, (hipStream_t) nullptr));
+    return temp.ensure(bytes);
+}
+
 int exclusive_scan_i32(hipStream_t stream, DevBuf& temp, const int32_t* in, int32_t* out, size_t n) {
     if (n == 0) return TKHIP_OK;
     size_t bytes = 0;
