@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override the image size of the scene (square)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses N > 1 on fewer GPUs")
     args = ap.parse_args()
 
     import torch
@@ -111,9 +112,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)   # rehearsal: ranks may share a GPU
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -140,7 +146,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -160,6 +166,8 @@ def main():
     times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"]],
                          dtype=torch.float64, device=dev)
     if world > 1:
+        if args.backend != "nccl":
+            vals, times = vals.cpu(), times.cpu()
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     vals = (vals / n_inst).tolist()

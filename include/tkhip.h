@@ -201,8 +201,17 @@ int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, cons
                                const uint16_t* dir, int64_t n, int64_t shot_total);
 
 /* PhotonMap::buildKdTree for both maps (src/tracer/Photonmap.cpp:96-103,
- * :132-179), as a sort-based median split on the device. */
+ * :132-179): the search tree of each map, here a balanced binary tree over the
+ * photons in Hilbert-curve order with tight boxes (a gather's result does not
+ * depend on the shape of the tree). */
 int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* stats);
+
+/* Starts the camera paths of iteration `iter` (the part of traceTile that does
+ * not read the photon maps, src/tracer/TkSppmTracer.cpp:296-321, :341-371) and
+ * returns at once; tkhip_sppm_camera_pass(iter) then picks them up.  Optional:
+ * lets a multi-GPU driver trace camera paths while photons are still being
+ * traced and exchanged. */
+int tkhip_sppm_camera_begin(tkhip_ctx* ctx, int iter);
 
 /* traceTile over this rank's pixels (src/tracer/TkSppmTracer.cpp:290-374):
  * camera paths with next-event estimation, the caustic and global gathers

@@ -95,6 +95,7 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_set_map_photons": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_int64]),
     "tkhip_sppm_build_maps": (C.c_int, [C.c_void_p, C.POINTER(TkIterStats)]),
+    "tkhip_sppm_camera_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_camera_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_read_pixels": (C.c_int, [C.c_void_p, C.POINTER(TkSPPMPixel)]),

@@ -66,6 +66,7 @@ struct SppmState {
     DevBuf loc_pos[2], loc_pow[2], loc_dir[2];
     int64_t n_loc[2] = {0, 0}, last_shot[2] = {0, 0}, local_shot[2] = {0, 0}, shoot[2] = {0, 0};
     int64_t stored_c = 0;
+    int camera_in_flight = -1;       // iteration whose camera paths have been launched and not yet waited for
     int64_t caustic_hoff = 0;        // global paths shot before the current iteration
     double yield[2] = {2.0, 0.05};
     // pixels
@@ -781,12 +782,13 @@ static int install_local(tkhip_ctx* ctx, int which) {
 // planes, gather queries into the two query buffers.  The photon maps are not
 // read here, so this runs beside the photon passes.  expect_caustic: emit
 // caustic queries (they are dropped later if the caustic map stays empty).
-static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
+static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     SppmState* s = ctx->sppm;
     Lane& ln = s->lane[2];
     hipStream_t stream = ln.stream;
     int32_t* counters = ln.counters.as<int32_t>();
     s->n_queries[0] = s->n_queries[1] = 0;
+    s->camera_in_flight = iter;
     if (s->n_slots == 0) return TKHIP_OK;
     CameraArgs a;
     a.sc = ctx->scene; a.cam = ctx->cam;
@@ -808,10 +810,22 @@ static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
-    TK_HIP(hipStreamSynchronize(stream));
+    return TKHIP_OK;
+}
+// Waits for the camera paths launched last and takes their query counts.
+static int camera_trace_wait(tkhip_ctx* ctx) {
+    SppmState* s = ctx->sppm;
+    Lane& ln = s->lane[2];
+    s->camera_in_flight = -1;
+    if (s->n_slots == 0) return TKHIP_OK;
+    TK_HIP(hipStreamSynchronize(ln.stream));
     s->n_queries[0] = ln.h_counters[C_NGQ];
     s->n_queries[1] = ln.h_counters[C_NCQ];
     return TKHIP_OK;
+}
+static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
+    TK_TRY(camera_trace_launch(ctx, iter, expect_caustic));
+    return camera_trace_wait(ctx);
 }
 
 // radiance_estimate + SPPMPixel update for the queries of one map, on that
@@ -1081,12 +1095,23 @@ int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* st) {
     return TKHIP_OK;
 }
 
+int tkhip_sppm_camera_begin(tkhip_ctx* ctx, int iter) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_camera_begin");
+    SppmState* s = ctx->sppm;
+    if (s->camera_in_flight >= 0) TK_TRY(camera_trace_wait(ctx));
+    return camera_trace_launch(ctx, iter, s->prm.causticSize > 0);
+}
+
 int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_camera_pass");
     SppmState* s = ctx->sppm;
     TK_REQUIRE(s->map[0]->built, TKHIP_E_STATE, "tkhip_sppm_camera_pass: build the photon maps first");
     double t0 = now_ms();
-    TK_TRY(camera_trace(ctx, iter, s->stored_c > 0));
+    if (s->camera_in_flight == iter) TK_TRY(camera_trace_wait(ctx));   // started by tkhip_sppm_camera_begin
+    else {
+        if (s->camera_in_flight >= 0) TK_TRY(camera_trace_wait(ctx));
+        TK_TRY(camera_trace(ctx, iter, s->prm.causticSize > 0));
+    }
     if (st) st->ms_camera += (float)(now_ms() - t0);
     TK_TRY(gather_both(ctx, st));
     TK_TRY(collect_rays(ctx, 2, st));

@@ -84,6 +84,9 @@ class HipBackend:
     def build_maps(self, stats=None):
         self.tracer.build_maps(stats)
 
+    def camera_begin(self, it):
+        check(self.lib, self.lib.tkhip_sppm_camera_begin(self.h, it), "tkhip_sppm_camera_begin")
+
     def camera_pass(self, it, stats=None):
         self.tracer.camera_pass(it, stats)
 
@@ -104,21 +107,36 @@ class HipBackend:
         self.tracer.close()
 
 
+def _on_host(t):
+    """gloo (used to rehearse the multi-rank path where RCCL cannot run, e.g. several ranks on one GPU) gathers
+    host tensors only; RCCL takes the device tensors as they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather(t, world):
+    if _on_host(t):
+        h = t.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h)
+        return [p.to(t.device) for p in parts]
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous())
+    return parts
+
+
 def exchange_photons(backend, which, world):
     """All-gather of one map's photons and sum of its shot counters.  Returns (n_total, shot_total)."""
     if world == 1:
         return None   # a single rank installs its own photons at the end of its photon pass
     pos, power, direction, n, shot = backend.export_local(which)
     meta = torch.tensor([n, shot], dtype=torch.int64, device=pos.device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
+    metas = _all_gather(meta, world)
     counts = [int(m[0]) for m in metas]
     shot_total = sum(int(m[1]) for m in metas)
     gathered = []
     # the two direction bytes travel as int32: neither RCCL nor gloo reduces or gathers int16
     for t in (pos, power, direction.to(torch.int32)):
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t.contiguous())
+        parts = _all_gather(t.contiguous(), world)
         gathered.append(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).contiguous())
     n_total = sum(counts)
     backend.set_map(which, gathered[0], gathered[1], gathered[2].to(torch.int16).contiguous(), n_total, shot_total)
@@ -126,10 +144,12 @@ def exchange_photons(backend, which, world):
 
 
 def iteration(backend, it, world, stats=None):
-    """photon pass -> exchange -> tree builds -> camera pass, for every rank in lockstep."""
+    """photon pass -> exchange -> tree builds -> camera pass (gathers), for every rank in lockstep."""
     if world == 1 and hasattr(backend, "iteration_single"):
         backend.iteration_single(it, stats)
         return [None, None]
+    if hasattr(backend, "camera_begin"):
+        backend.camera_begin(it)   # camera paths do not read the maps: trace them beside the photon phase
     backend.photon_pass(it, stats)
     totals = [exchange_photons(backend, which, world) for which in (0, 1)]
     backend.build_maps(stats)
@@ -142,8 +162,14 @@ def gather_planes(backend, rank, world, height):
     planes = backend.export_planes()
     if world == 1:
         return planes
-    parts = [torch.empty_like(planes) for _ in range(world)] if rank == 0 else None
-    dist.gather(planes, parts, dst=0)
+    if _on_host(planes):
+        host = planes.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, parts, dst=0)
+        parts = [p.to(planes.device) for p in parts] if rank == 0 else None
+    else:
+        parts = [torch.empty_like(planes) for _ in range(world)] if rank == 0 else None
+        dist.gather(planes, parts, dst=0)
     if rank != 0:
         return None
     owner = torch.tensor([row_owner(y, world) for y in range(height)], device=planes.device)
