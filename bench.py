@@ -15,6 +15,7 @@ photon maps are all-gathered over RCCL every iteration.
 Prints one JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -137,14 +138,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    lib, ctx_h = backend.lib, backend.h
+
+    def gather_totals(reset):
+        t = _abi.TkGatherTotals()
+        _abi.check(lib, lib.tkhip_sppm_gather_totals(ctx_h, C.byref(t), 1 if reset else 0), "tkhip_sppm_gather_totals")
+        return t
+
     for it in range(args.warmup):
         D.iteration(backend, it, world)
     sync()
+    gather_totals(True)   # the grouped gather kernel is event-timed on its stream at every launch: count from here
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
         D.iteration(backend, it, world)
     sync()
     elapsed = time.perf_counter() - t0
+    gt = gather_totals(True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,9 +171,12 @@ def main():
     sync()
     vals = torch.tensor([acc["rays"], acc["gathers_global"], acc["gathers_caustic"], acc["gather_photons"],
                          acc["overflow_global"], acc["overflow_caustic"], acc["global_paths"], acc["caustic_paths"],
-                         acc["group_staged"]],
+                         acc["group_staged"],
+                         n_inst * gt.queries, n_inst * gt.queries_handed_on_k[0], n_inst * gt.queries_handed_on_k[1],
+                         n_inst * gt.photons_found, n_inst * gt.photons_staged, n_inst * gt.launches],
                         dtype=torch.float64, device=dev)
-    times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"]],
+    times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"],
+                          n_inst * gt.ms_group_kernel],
                          dtype=torch.float64, device=dev)
     if world > 1:
         if args.backend != "nccl":
@@ -172,8 +185,8 @@ def main():
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     vals = (vals / n_inst).tolist()
     times = (times / n_inst).tolist()
-    rays, ng, nc, phot, og, oc, gpaths, cpaths, staged = vals
-    ms_group, ms_photon, ms_build, ms_camera, ms_gather = times
+    rays, ng, nc, phot, og, oc, gpaths, cpaths, staged, t_q, t_og, t_oc, t_phot, t_staged, t_launches = vals
+    ms_group, ms_photon, ms_build, ms_camera, ms_gather, t_ms = times
 
     if rank == 0:
         its = args.steps / elapsed
@@ -181,11 +194,27 @@ def main():
         # Algorithmic bytes of a gather: 56 B query + 26 B per photon found + 40 B pixel slice.
         # The grouped kernel finishes the gathers that met fewer than k photons; the others end
         # with exactly k photons in the per-query kernel and are not charged to it here.
+        # Measured over the timed region: every launch of the kernel is bracketed by HIP events on
+        # the stream it runs on (the two maps' launches of a step run side by side there).
         k_g, k_c = param.globalSample, param.causticSample
-        done = (ng - og) + (nc - oc)
-        phot_group = phot - k_g * og - k_c * oc
-        bytes_group = 96.0 * done + 26.0 * phot_group
-        achieved = bytes_group / (ms_group * 1e-3) / 1e9 if ms_group > 0 else 0.0
+        done = t_q - t_og - t_oc
+        phot_group = t_phot - k_g * t_og - k_c * t_oc
+        bytes_total = 96.0 * done + 26.0 * phot_group
+        launches = max(t_launches, 1.0)
+        bytes_launch = bytes_total / launches
+        avg_launch_ms = t_ms / (launches / world)   # t_ms is the slowest rank's sum over its own launches
+        achieved = bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        # the same kernel with the GPU to itself (instrumented iterations after the timed region)
+        alone_bytes = 96.0 * ((ng - og) + (nc - oc)) + 26.0 * (phot - k_g * og - k_c * oc)
+        alone = alone_bytes / (ms_group * 1e-3) / 1e9 if ms_group > 0 else 0.0
+        # HBM traffic of the kernel comes from PMC passes of their own (FETCH_SIZE, WRITE_SIZE), which cannot
+        # run inside this process: the last collection is kept under profiles/ with its provenance.
+        traffic, traffic_note = None, None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if world == 1 and args.scene == WORKLOAD and not args.size and os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic, traffic_note = tj.get("bytes_per_launch"), tj.get("note")
         out = {
             "metric": "SPPM iterations/sec", "value": its, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -200,11 +229,14 @@ def main():
             "phase_ms": {"photon": ms_photon, "kd_build": ms_build, "camera": ms_camera, "gather": ms_gather,
                          "gather_group_kernel": ms_group},
             "roofline": {"bound": "hbm", "kernel": "k_gather_group", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launches_per_step": 2, "avg_launch_ms": ms_group / 2.0,
-                         "algorithmic_bytes_per_step": bytes_group,
-                         "gathers_finished": done, "gathers_to_selection_kernel": og + oc,
-                         "distance_tests_per_gather": staged * 64.0 / max(ng + nc, 1.0)},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "launches": launches / world, "avg_launch_ms": avg_launch_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "gathers_per_launch": t_q / launches, "finished_per_launch": done / launches,
+                         "distance_tests_per_gather": t_staged * 64.0 / max(t_q, 1.0),
+                         "alone": {"achieved": alone, "frac": alone / HBM_PEAK_GBS, "avg_launch_ms": ms_group / 2.0,
+                                   "note": "the same kernel with the GPU to itself (instrumented iterations after the "
+                                           "timed region, the two maps one after the other)"}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, param, max_depth, rr, seed, args.cpu_threads)

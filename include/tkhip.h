@@ -206,6 +206,22 @@ int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, cons
  * depend on the shape of the tree). */
 int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* stats);
 
+/* Running totals of the grouped gather kernel (the kernel that answers
+ * radiance_estimate, src/tracer/Photonmap.cpp:105-130, for the queries that
+ * meet fewer than k photons) over all tkhip_sppm_* gathers since the last
+ * reset: every launch is bracketed by events on its stream.  For benchmarks. */
+typedef struct TkGatherTotals {
+    int64_t launches;            /* grouped-kernel launches (one per map and gather) */
+    int64_t queries;             /* queries given to them */
+    int64_t queries_handed_on;   /* of those, finished by the per-query kernel instead */
+    int64_t photons_found;       /* sum of `found` over all queries (both kernels) */
+    int64_t photons_staged;      /* photons the grouped kernel staged, summed over waves */
+    int64_t photons_found_k[2];      /* per map: global, caustic */
+    int64_t queries_handed_on_k[2];
+    double ms_group_kernel;      /* summed event-timed durations of the launches */
+} TkGatherTotals;
+int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset);
+
 /* Starts the camera paths of iteration `iter` (the part of traceTile that does
  * not read the photon maps, src/tracer/TkSppmTracer.cpp:296-321, :341-371) and
  * returns at once; tkhip_sppm_camera_pass(iter) then picks them up.  Optional:

@@ -67,6 +67,12 @@ class TkIterStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class TkGatherTotals(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("queries", C.c_int64), ("queries_handed_on", C.c_int64),
+                ("photons_found", C.c_int64), ("photons_staged", C.c_int64), ("photons_found_k", C.c_int64 * 2),
+                ("queries_handed_on_k", C.c_int64 * 2), ("ms_group_kernel", C.c_double)]
+
+
 class TkTracerConfig(C.Structure):
     _fields_ = [("type", C.c_char * 16), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("num_threads", C.c_int32), ("russian_roulette", C.c_float), ("sppm", TkSppmParam)]
@@ -96,6 +102,7 @@ TKHIP_SYMBOLS = {
                                              C.c_int64, C.c_int64]),
     "tkhip_sppm_build_maps": (C.c_int, [C.c_void_p, C.POINTER(TkIterStats)]),
     "tkhip_sppm_camera_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "tkhip_sppm_gather_totals": (C.c_int, [C.c_void_p, C.POINTER(TkGatherTotals), C.c_int]),
     "tkhip_sppm_camera_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_read_pixels": (C.c_int, [C.c_void_p, C.POINTER(TkSPPMPixel)]),

@@ -26,6 +26,7 @@ struct GatherOut {
     int32_t which;      // 0 global, 1 caustic: selects the planes to update
     unsigned long long* photon_sum;   // optional: sum of found over queries
     unsigned long long* cand_sum;     // optional: photons staged by the grouped kernel, summed over waves (x64 = tests)
+    unsigned long long* overflow_sum; // optional: queries handed to the per-query kernel
 };
 
 struct MapView {
@@ -52,6 +53,14 @@ struct tkhip_map {
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
     float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)
     int64_t last_overflow = 0;   // queries the last timed gather handed to the per-query kernel
+    // Every grouped-kernel launch is bracketed by this pair of events on the map's stream (recording
+    // costs nothing worth naming); the pair of the launch before is read back when the next one is
+    // recorded or when the totals are asked for.
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool ev_pending = false;
+    double group_ms_total = 0.0;
+    int64_t group_launches = 0, group_queries = 0;
+    tkd::DevBuf totals;          // 3 x u64 on the device: photons found, photons staged, queries handed on
     tkd::MapView view() const;
 };
 
@@ -67,6 +76,8 @@ int map_build(tkhip_map* m);
 // grouped kernel's duration with events (synchronises).
 // Sizes the scratch of gathers of up to nq queries (so that later gathers do not reallocate).
 int map_reserve_queries(tkhip_map* m, int64_t nq);
+// Adds the pending event pair to the running totals (waits for the launch it brackets).
+int map_flush_timing(tkhip_map* m);
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed);
 
 }  // namespace tkd

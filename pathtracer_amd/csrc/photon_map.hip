@@ -485,6 +485,8 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         found_sum += (unsigned long long)count;
     }
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
+    if (out.overflow_sum && list && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(out.overflow_sum, (unsigned long long)*list_count);
 }
 
 // ---------------------------------------- grouped kernel (64 queries per wave)
@@ -664,6 +666,12 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
     if (!rc) rc = m->in_pow.ensure(c * 12);
     if (!rc) rc = m->in_dir.ensure(c * 2);
     if (!rc) rc = m->counters.ensure(64);
+    if (!rc) rc = m->totals.ensure(32);
+    if (!rc && hipMemset(m->totals.p, 0, 32) != hipSuccess) { set_error("map_create: memset failed"); rc = TKHIP_E_HIP; }
+    if (!rc && (hipEventCreate(&m->ev_begin) != hipSuccess || hipEventCreate(&m->ev_end) != hipSuccess)) {
+        set_error("map_create: hipEventCreate failed");
+        rc = TKHIP_E_HIP;
+    }
     if (!rc) rc = upload_direction_tables(ctx);
     if (rc) { map_destroy(m); return rc; }
     *out = m;
@@ -675,6 +683,9 @@ void map_destroy(tkhip_map* m) {
     DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
                       &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters, &m->prim_temp};
     for (DevBuf* b : bufs) b->release();
+    m->totals.release();
+    if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
+    if (m->ev_end) (void)hipEventDestroy(m->ev_end);
     delete m;
 }
 
@@ -769,6 +780,17 @@ int map_reserve_queries(tkhip_map* m, int64_t nq) {
     return TKHIP_OK;
 }
 
+int map_flush_timing(tkhip_map* m) {
+    if (!m->ev_pending) return TKHIP_OK;
+    float ms = 0.f;
+    TK_HIP(hipEventSynchronize(m->ev_end));
+    TK_HIP(hipEventElapsedTime(&ms, m->ev_begin, m->ev_end));
+    m->group_ms_total += ms;
+    m->group_launches += 1;
+    m->ev_pending = false;
+    return TKHIP_OK;
+}
+
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed) {
     TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
     if (nq == 0) return TKHIP_OK;
@@ -796,12 +818,8 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
                           m->q_order.as<uint32_t>(), (size_t)nq, 30));
     int32_t* ocount = m->counters.as<int32_t>();
     TK_HIP(hipMemsetAsync(ocount, 0, 4, s));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed) {
-        TK_HIP(hipEventCreate(&e0));
-        TK_HIP(hipEventCreate(&e1));
-        TK_HIP(hipEventRecord(e0, s));
-    }
+    TK_TRY(map_flush_timing(m));
+    TK_HIP(hipEventRecord(m->ev_begin, s));
     const int64_t groups = (nq + 63) / 64;
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), 256 * 32);
     if (out.idx)
@@ -811,12 +829,12 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
                                                      m->overflow.as<int32_t>(), ocount);
     TK_LAUNCH_CHECK();
+    TK_HIP(hipEventRecord(m->ev_end, s));
+    m->ev_pending = true;
+    m->group_queries += nq;
     if (timed) {
-        TK_HIP(hipEventRecord(e1, s));
-        TK_HIP(hipEventSynchronize(e1));
-        TK_HIP(hipEventElapsedTime(&m->last_group_ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        TK_HIP(hipEventSynchronize(m->ev_end));
+        TK_HIP(hipEventElapsedTime(&m->last_group_ms, m->ev_begin, m->ev_end));
     }
     wave_all(m->overflow.as<int32_t>(), ocount, nq);
     TK_LAUNCH_CHECK();

@@ -66,6 +66,7 @@ struct SppmState {
     DevBuf loc_pos[2], loc_pow[2], loc_dir[2];
     int64_t n_loc[2] = {0, 0}, last_shot[2] = {0, 0}, local_shot[2] = {0, 0}, shoot[2] = {0, 0};
     int64_t stored_c = 0;
+    int64_t last_gather_photons[2] = {0, 0}, last_gather_staged[2] = {0, 0};   // of the last timed gather
     int camera_in_flight = -1;       // iteration whose camera paths have been launched and not yet waited for
     int64_t caustic_hoff = 0;        // global paths shot before the current iteration
     double yield[2] = {2.0, 0.05};
@@ -842,11 +843,25 @@ static int camera_gather(tkhip_ctx* ctx, int which, bool timed) {
     out.planes = s->planes.as<float>();
     out.n_pixels = s->n_pixels;
     out.which = which;
-    out.photon_sum = reinterpret_cast<unsigned long long*>(&s->lane[which].counters.as<int32_t>()[C_PHOT]);
-    out.cand_sum = reinterpret_cast<unsigned long long*>(&s->lane[which].counters.as<int32_t>()[C_CAND]);
-    TK_HIP(hipMemsetAsync(out.photon_sum, 0, 16, s->map[which]->stream));
+    // running totals of the map (read by tkhip_sppm_gather_totals and, per call, by the stats below)
+    unsigned long long* totals = s->map[which]->totals.as<unsigned long long>();
+    out.photon_sum = totals;
+    out.cand_sum = totals + 1;
+    out.overflow_sum = totals + 2;
+    unsigned long long before[2] = {0, 0};
+    if (timed) {
+        TK_HIP(hipMemcpyAsync(before, totals, 16, hipMemcpyDeviceToHost, s->map[which]->stream));
+        TK_HIP(hipStreamSynchronize(s->map[which]->stream));
+    }
     TK_TRY(map_gather_device(s->map[which], nq, qv, out, 0, timed));
     TK_HIP(hipStreamSynchronize(s->map[which]->stream));
+    if (timed) {
+        unsigned long long after[2] = {0, 0};
+        TK_HIP(hipMemcpyAsync(after, totals, 16, hipMemcpyDeviceToHost, s->map[which]->stream));
+        TK_HIP(hipStreamSynchronize(s->map[which]->stream));
+        s->last_gather_photons[which] = (int64_t)(after[0] - before[0]);
+        s->last_gather_staged[which] = (int64_t)(after[1] - before[1]);
+    }
     return TKHIP_OK;
 }
 
@@ -910,11 +925,9 @@ static int gather_both(tkhip_ctx* ctx, TkIterStats* st) {
         st->gathers_global += s->n_queries[0];
         st->gathers_caustic += s->n_queries[1];
         for (int which = 0; which < 2; ++which) {
-            int64_t phot = 0, cand = 0;
-            TK_TRY(read_u64_counter(s->lane[which], C_PHOT, &phot));
-            TK_TRY(read_u64_counter(s->lane[which], C_CAND, &cand));
-            st->gather_photons += phot;
-            st->group_staged += cand;
+            if (s->n_queries[which] == 0) continue;
+            st->gather_photons += s->last_gather_photons[which];
+            st->group_staged += s->last_gather_staged[which];
         }
     }
     return TKHIP_OK;
@@ -1177,6 +1190,33 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         st->ms_total += (float)(now_ms() - t0);
         fill_photon_stats(s, st);
     }
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_gather_totals");
+    SppmState* s = ctx->sppm;
+    TkGatherTotals t{};
+    for (int which = 0; which < 2; ++which) {
+        tkhip_map* m = s->map[which];
+        TK_HIP(hipStreamSynchronize(m->stream));
+        TK_TRY(map_flush_timing(m));
+        unsigned long long dev[3] = {0, 0, 0};
+        TK_HIP(hipMemcpy(dev, m->totals.p, sizeof(dev), hipMemcpyDeviceToHost));
+        t.launches += m->group_launches;
+        t.ms_group_kernel += m->group_ms_total;
+        t.queries += m->group_queries;
+        t.photons_found += (int64_t)dev[0];
+        t.photons_staged += (int64_t)dev[1];
+        t.queries_handed_on += (int64_t)dev[2];
+        t.photons_found_k[which] = (int64_t)dev[0];
+        t.queries_handed_on_k[which] = (int64_t)dev[2];
+        if (reset) {
+            TK_HIP(hipMemset(m->totals.p, 0, 32));
+            m->group_launches = 0; m->group_queries = 0; m->group_ms_total = 0.0;
+        }
+    }
+    if (out) *out = t;
     return TKHIP_OK;
 }
 
