@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default=WORKLOAD)
     ap.add_argument("--size", type=int, default=0, help="override the image size of the scene (square)")
+    ap.add_argument("--synthetic", type=int, default=0, metavar="QUADS",
+                    help="instead of a scene file: the Cornell shell with two spheres over a height field of QUADS x QUADS "
+                         "quads (2236 gives the 10 M-triangle configuration)")
+    ap.add_argument("--photons", type=int, nargs=2, default=None, metavar=("GLOBAL", "CAUSTIC"),
+                    help="override the photon map sizes of the scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses N > 1 on fewer GPUs")
@@ -125,10 +130,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
 
-    scene = Scene.load(asset_scene(args.scene))
+    scene = Scene.synthetic(args.synthetic) if args.synthetic else Scene.load(asset_scene(args.scene))
+    if args.synthetic:
+        args.scene = f"synthetic height field {args.synthetic}x{args.synthetic} quads ({scene.n_triangles} triangles)"
     W = args.size or scene.width
     H = args.size or scene.height
-    param = scene.sppm_param()
+    param = scene.sppm_param(globalSize=args.photons[0], causticSize=args.photons[1]) if args.photons else scene.sppm_param()
     max_depth, rr, seed = scene.tracer.max_depth, scene.tracer.russian_roulette, 0x5EED
     backend = D.HipBackend(scene, param, max_depth, rr, seed, W, H, rank, world, local_rank)
 

@@ -34,8 +34,9 @@ TKD uint32_t f2ord(float f) {
 }
 TKD float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-TKD int64_t leaf_start(int64_t j, int64_t n, int64_t nl) { return j * n / nl; }
-TKD int leaf_of_pos(int64_t i, int64_t n, int64_t nl) { return (int)(((i + 1) * nl - 1) / n); }
+// First photon of leaf j: the n photons are dealt evenly to the 2^depth leaves.  A shift, not a
+// division: the gather kernels evaluate this for every leaf they touch.
+TKD int64_t leaf_start(int64_t j, int64_t n, int depth) { return (j * n) >> depth; }
 
 TKD float dist2_exact(float px, float py, float pz, F3 q) {
     float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
@@ -147,10 +148,10 @@ __global__ void k_permute(const float* pos, const float* pow, const uint16_t* di
                           __uint_as_float((uint32_t)dir[s]));
 }
 
-__global__ void k_leaf_boxes(const float4* pos4, float4* node_box, int64_t n, int nl) {
+__global__ void k_leaf_boxes(const float4* pos4, float4* node_box, int64_t n, int nl, int depth) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nl) return;
-    int64_t s = leaf_start(j, n, nl), e = leaf_start(j + 1, n, nl);
+    int64_t s = leaf_start(j, n, depth), e = leaf_start(j + 1, n, depth);
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = s; i < e; ++i) {
         float4 p = pos4[i];
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
             uint32_t at = 0;
             if (node > 0) {
                 const int leaf = node - mv.nl;
-                const int64_t s0 = leaf_start(leaf, mv.n, mv.nl), e0 = leaf_start(leaf + 1, mv.n, mv.nl);
+                const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
                 if (ph < (int)(e0 - s0)) {
                     at = (uint32_t)(s0 + ph);
                     float4 pp = mv.pos4[at];
@@ -582,9 +583,9 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
                 auto fetch = [&](int i, float4* pp, float4* pw, int* na, int* nb) {
                     const int node_a = uniform_i(front[cur][i]);
                     const int node_b = i + 1 < fcount ? uniform_i(front[cur][i + 1]) : 0;
-                    const int64_t sa = leaf_start(node_a - mv.nl, mv.n, mv.nl), ea = leaf_start(node_a - mv.nl + 1, mv.n, mv.nl);
+                    const int64_t sa = leaf_start(node_a - mv.nl, mv.n, mv.depth), ea = leaf_start(node_a - mv.nl + 1, mv.n, mv.depth);
                     int64_t sb = 0, eb = 0;
-                    if (node_b) { sb = leaf_start(node_b - mv.nl, mv.n, mv.nl); eb = leaf_start(node_b - mv.nl + 1, mv.n, mv.nl); }
+                    if (node_b) { sb = leaf_start(node_b - mv.nl, mv.n, mv.depth); eb = leaf_start(node_b - mv.nl + 1, mv.n, mv.depth); }
                     *na = (int)(ea - sa);
                     *nb = (int)(eb - sb);
                     const int64_t at = half ? sb + ph : sa + ph;
@@ -739,7 +740,7 @@ int map_build(tkhip_map* m) {
                           m->idx_a.as<uint32_t>(), (size_t)n, 30));   // idx_a: the leaf order
     k_permute<<<divup(n, B), B, 0, s>>>(pos, m->in_pow.as<float>(), m->in_dir.as<uint16_t>(), m->idx_a.as<uint32_t>(),
                                         m->pos4.as<float4>(), m->pow4.as<float4>(), n);
-    k_leaf_boxes<<<divup(nl, 64), 64, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl);
+    k_leaf_boxes<<<divup(nl, 64), 64, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl, depth);
     if (depth > 0) k_inner_boxes<<<1, 1024, 0, s>>>(m->node_box.as<float4>(), depth);
     TK_LAUNCH_CHECK();
     m->built = true;
