@@ -124,23 +124,40 @@ def _all_gather(t, world):
     return parts
 
 
-def exchange_photons(backend, which, world):
-    """All-gather of one map's photons and sum of its shot counters.  Returns (n_total, shot_total)."""
+def exchange_photons(backend, world):
+    """All-gather of both maps' photons and sum of their shot counters, as ONE collective per iteration: each
+    rank sends an int32 table of 7 columns (position and power bit-cast, the two direction bytes) with a
+    header row (photon counts and shot counters of both maps).  Returns [(n_total, shot_total)] per map."""
     if world == 1:
-        return None   # a single rank installs its own photons at the end of its photon pass
-    pos, power, direction, n, shot = backend.export_local(which)
-    meta = torch.tensor([n, shot], dtype=torch.int64, device=pos.device)
-    metas = _all_gather(meta, world)
-    counts = [int(m[0]) for m in metas]
-    shot_total = sum(int(m[1]) for m in metas)
-    gathered = []
-    # the two direction bytes travel as int32: neither RCCL nor gloo reduces or gathers int16
-    for t in (pos, power, direction.to(torch.int32)):
-        parts = _all_gather(t.contiguous(), world)
-        gathered.append(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).contiguous())
-    n_total = sum(counts)
-    backend.set_map(which, gathered[0], gathered[1], gathered[2].to(torch.int16).contiguous(), n_total, shot_total)
-    return n_total, shot_total
+        return [None, None]   # a single rank installs its own photons at the end of its photon pass
+    parts = [backend.export_local(which) for which in (0, 1)]
+    caps = [p[0].shape[0] for p in parts]
+    dev = parts[0][0].device
+    table = torch.zeros((1 + caps[0] + caps[1], 7), dtype=torch.int32, device=dev)
+    head = []
+    for pos, power, direction, n, shot in parts:
+        head += [n, shot & 0x7FFFFFFF, shot >> 31]
+    table[0, :6] = torch.tensor(head, dtype=torch.int32)
+    row = 1
+    for (pos, power, direction, n, shot), cap in zip(parts, caps):
+        table[row:row + cap, 0:3] = pos.contiguous().view(torch.int32)
+        table[row:row + cap, 3:6] = power.contiguous().view(torch.int32)
+        table[row:row + cap, 6] = direction.to(torch.int32)   # neither RCCL nor gloo gathers int16
+        row += cap
+    tables = _all_gather(table, world)
+    heads = torch.stack([t[0, :6] for t in tables]).cpu().tolist()
+    totals = []
+    row = 1
+    for which, cap in enumerate(caps):
+        counts = [int(h[3 * which]) for h in heads]
+        shot_total = sum(int(h[3 * which + 1]) + (int(h[3 * which + 2]) << 31) for h in heads)
+        rows = torch.cat([t[row:row + c] for t, c in zip(tables, counts)], dim=0)
+        n_total = sum(counts)
+        backend.set_map(which, rows[:, 0:3].contiguous().view(torch.float32), rows[:, 3:6].contiguous().view(torch.float32),
+                        rows[:, 6].to(torch.int16).contiguous(), n_total, shot_total)
+        totals.append((n_total, shot_total))
+        row += cap
+    return totals
 
 
 def iteration(backend, it, world, stats=None):
@@ -151,7 +168,7 @@ def iteration(backend, it, world, stats=None):
     if hasattr(backend, "camera_begin"):
         backend.camera_begin(it)   # camera paths do not read the maps: trace them beside the photon phase
     backend.photon_pass(it, stats)
-    totals = [exchange_photons(backend, which, world) for which in (0, 1)]
+    totals = exchange_photons(backend, world)
     backend.build_maps(stats)
     backend.camera_pass(it, stats)
     return totals
