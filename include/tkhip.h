@@ -206,6 +206,22 @@ int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, cons
  * depend on the shape of the tree). */
 int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* stats);
 
+/* Material::sample_f for n (wo, N, u) triples on one material
+ * (src/core/Material.cpp:22-95; DiffuseMaterial, MirrorMaterial, GlassMaterial).
+ * mode 0 = TransportMode Radiance, 1 = Importance.  Host buffers: wo, nrm, wi, f
+ * 3 floats per sample, u 2, pdf 1.  For parity tests. */
+int tkhip_sample_f(tkhip_ctx* ctx, const TkMaterial* material, int mode, int64_t n, const float* wo,
+                   const float* nrm, const float* u, float* wi, float* f, float* pdf);
+
+/* AreaLight::sample_Le on light `light` of the scene (src/Light.cpp:41-75) with
+ * the triangle pick of MeshTriangle::Sample (src/Triangle.cpp:190-197) drawn
+ * from upick: u1 places the point, u2 the direction.  Returns the spawned ray
+ * (offset origin, direction), the light normal, Le and the two pdfs.  Host
+ * buffers.  For parity tests. */
+int tkhip_sample_le(tkhip_ctx* ctx, int light, int64_t n, const float* u1, const float* u2,
+                    const float* upick, float* org, float* dir, float* nrm, float* le, float* pdf_pos,
+                    float* pdf_dir);
+
 /* Running totals of the grouped gather kernel (the kernel that answers
  * radiance_estimate, src/tracer/Photonmap.cpp:105-130, for the queries that
  * meet fewer than k photons) over all tkhip_sppm_* gathers since the last

@@ -123,6 +123,10 @@ TKHIP_SYMBOLS = {
                                      c_int32_p, c_float_p]),
     "tkhip_radical_inverse": (C.c_int, [C.c_void_p, C.c_int64, c_int32_p, c_uint64_p, c_float_p]),
     "tkhip_camera_rays": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p]),
+    "tkhip_sample_f": (C.c_int, [C.c_void_p, C.POINTER(TkMaterial), C.c_int, C.c_int64, c_float_p, c_float_p, c_float_p,
+                                 c_float_p, c_float_p, c_float_p]),
+    "tkhip_sample_le": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                  c_float_p, c_float_p, c_float_p, c_float_p]),
     "tkhip_sppm_read_photons": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_uint8_p, c_uint8_p,
                                           c_int64_p]),
 }

@@ -144,29 +144,11 @@ TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
     P.uby = radical_inverse(6, H);
     const DLight L = sc.lights[li];
     const float upick = photon_rng(a.seed, H, KIND, 0, 0);
-    float pd, tmp;
-    const int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, upick, &pd);
-    LightPoint lp = tri_sample(sc, L.tri_first + idx, u0x, u0y, &tmp);
-    const float pos_pdf = pd * tmp;
-    float dir_pdf;
-    F3 w;
-    if (L.two_sided) {
-        float ux = u1x;
-        if (ux < 0.5f) { ux = sse_min(ux * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); }
-        else { ux = sse_min((ux - 0.5f) * 2, kOneMinusEps); w = cosine_hemisphere(ux, u1y); w.z *= -1; }
-        dir_pdf = 0.5f * (fabsf(w.z) * kInvPi);
-    } else {
-        w = cosine_hemisphere(u1x, u1y);
-        dir_pdf = w.z * kInvPi;
-    }
-    F3 v1, v2;
-    coordinate_system(lp.n, &v1, &v2);
-    w = add3(add3(scale3(v1, w.x), scale3(v2, w.y)), scale3(lp.n, w.z));
-    const F3 Le = light_L(L, lp.n, w);
-    if (pos_pdf == 0 || dir_pdf == 0) return false;
-    P.power = divs3(scale3(Le, absdot3(w, lp.n)), pos_pdf * dir_pdf * pdf);
-    P.o = offset_ray_origin(lp.p, lp.perr, lp.n, w);
-    P.d = w;
+    const LightEmission e = light_sample_le(sc, L, u0x, u0y, u1x, u1y, upick);
+    if (e.pdf_pos == 0 || e.pdf_dir == 0) return false;
+    P.power = divs3(scale3(e.Le, absdot3(e.d, e.n)), e.pdf_pos * e.pdf_dir * pdf);
+    P.o = e.o;
+    P.d = e.d;
     P.flags = 0;
     return true;
 }

@@ -248,6 +248,83 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     return TKHIP_OK;
 }
 
+namespace tkd {
+__global__ void k_sample_f(TkMaterial m, int mode, int64_t n, const float* wo, const float* nrm, const float* u, float* wi,
+                           float* f, float* pdf) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 w;
+    float p;
+    F3 fv = mat_sample_f(m, mode != 0, ld3(wo + 3 * i), &w, ld3(nrm + 3 * i), u[2 * i], u[2 * i + 1], &p);
+    wi[3 * i] = w.x; wi[3 * i + 1] = w.y; wi[3 * i + 2] = w.z;
+    f[3 * i] = fv.x; f[3 * i + 1] = fv.y; f[3 * i + 2] = fv.z;
+    pdf[i] = p;
+}
+__global__ void k_sample_le(DScene sc, int li, int64_t n, const float* u1, const float* u2, const float* upick, float* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LightEmission e = light_sample_le(sc, sc.lights[li], u1[2 * i], u1[2 * i + 1], u2[2 * i], u2[2 * i + 1], upick[i]);
+    float* o = out + 14 * i;
+    o[0] = e.o.x; o[1] = e.o.y; o[2] = e.o.z; o[3] = e.d.x; o[4] = e.d.y; o[5] = e.d.z;
+    o[6] = e.n.x; o[7] = e.n.y; o[8] = e.n.z; o[9] = e.Le.x; o[10] = e.Le.y; o[11] = e.Le.z;
+    o[12] = e.pdf_pos; o[13] = e.pdf_dir;
+}
+}  // namespace tkd
+
+int tkhip_sample_f(tkhip_ctx* ctx, const TkMaterial* material, int mode, int64_t n, const float* wo, const float* nrm,
+                   const float* u, float* wi, float* f, float* pdf) {
+    TK_REQUIRE(ctx && material && wo && nrm && u && wi && f && pdf, TKHIP_E_ARG, "tkhip_sample_f: null argument");
+    TK_REQUIRE(n >= 0, TKHIP_E_ARG, "tkhip_sample_f: negative count");
+    TK_REQUIRE(material->type == TK_DIFFUSE || material->type == TK_MIRROR || material->type == TK_GLASS, TKHIP_E_ARG,
+               "tkhip_sample_f: unsupported material type %d", material->type);
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TK_TRY(ctx->scratch_a.ensure((size_t)n * 8 * 4));    // wo 3, n 3, u 2
+    TK_TRY(ctx->scratch_b.ensure((size_t)n * 7 * 4));    // wi 3, f 3, pdf 1
+    float* in = ctx->scratch_a.as<float>();
+    float* out = ctx->scratch_b.as<float>();
+    TK_HIP(hipMemcpyAsync(in, wo, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(in + 3 * n, nrm, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(in + 6 * n, u, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    k_sample_f<<<divup(n, 256), 256, 0, s>>>(*material, mode, n, in, in + 3 * n, in + 6 * n, out, out + 3 * n, out + 6 * n);
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(wi, out, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipMemcpyAsync(f, out + 3 * n, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipMemcpyAsync(pdf, out + 6 * n, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    return TKHIP_OK;
+}
+
+int tkhip_sample_le(tkhip_ctx* ctx, int light, int64_t n, const float* u1, const float* u2, const float* upick, float* org,
+                    float* dir, float* nrm, float* le, float* pdf_pos, float* pdf_dir) {
+    TK_REQUIRE(ctx && u1 && u2 && upick && org && dir && nrm && le && pdf_pos && pdf_dir, TKHIP_E_ARG,
+               "tkhip_sample_le: null argument");
+    TK_REQUIRE(ctx->has_scene, TKHIP_E_STATE, "tkhip_sample_le: set the scene first");
+    TK_REQUIRE(light >= 0 && light < ctx->scene.n_lights, TKHIP_E_ARG, "tkhip_sample_le: light %d out of range", light);
+    TK_REQUIRE(n >= 0, TKHIP_E_ARG, "tkhip_sample_le: negative count");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TK_TRY(ctx->scratch_a.ensure((size_t)n * 5 * 4));
+    TK_TRY(ctx->scratch_b.ensure((size_t)n * 14 * 4));
+    float* in = ctx->scratch_a.as<float>();
+    TK_HIP(hipMemcpyAsync(in, u1, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(in + 2 * n, u2, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(in + 4 * n, upick, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    k_sample_le<<<divup(n, 256), 256, 0, s>>>(ctx->scene, light, n, in, in + 2 * n, in + 4 * n, ctx->scratch_b.as<float>());
+    TK_LAUNCH_CHECK();
+    std::vector<float> host((size_t)n * 14);
+    TK_HIP(hipMemcpyAsync(host.data(), ctx->scratch_b.p, host.size() * 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i) {
+        const float* o = &host[(size_t)i * 14];
+        for (int a = 0; a < 3; ++a) { org[3 * i + a] = o[a]; dir[3 * i + a] = o[3 + a]; nrm[3 * i + a] = o[6 + a]; le[3 * i + a] = o[9 + a]; }
+        pdf_pos[i] = o[12]; pdf_dir[i] = o[13];
+    }
+    return TKHIP_OK;
+}
+
 int tkhip_set_camera(tkhip_ctx* ctx, const float c2w[16], const float raster2cam[16], int width, int height) {
     TK_REQUIRE(ctx && c2w && raster2cam, TKHIP_E_ARG, "tkhip_set_camera: null argument");
     TK_REQUIRE(width >= 1 && height >= 1 && (int64_t)width * height < (int64_t)1 << 30, TKHIP_E_LIMIT,

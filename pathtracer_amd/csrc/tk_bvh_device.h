@@ -308,4 +308,38 @@ TKD F3 light_L(const DLight& l, F3 n, F3 w) {                  // src/Light.cpp:
     return (l.two_sided || dot3(n, w) > 0) ? ld3(l.Le) : mk3(0, 0, 0);
 }
 
+// AreaLight::sample_Le (src/Light.cpp:41-75) with MeshTriangle::Sample's
+// triangle pick drawn from `upick` (src/Triangle.cpp:190-197): a point on the
+// light, a cosine-distributed direction about its normal, the spawned ray.
+struct LightEmission {
+    F3 o, d, n, Le;
+    float pdf_pos, pdf_dir;
+};
+TKD LightEmission light_sample_le(const DScene& sc, const DLight& L, float u1x, float u1y, float u2x, float u2y,
+                                  float upick) {
+    LightEmission e;
+    float pd, tmp;
+    const int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, upick, &pd);
+    LightPoint lp = tri_sample(sc, L.tri_first + idx, u1x, u1y, &tmp);
+    e.pdf_pos = pd * tmp;
+    F3 w;
+    if (L.two_sided) {
+        float ux = u2x;
+        if (ux < 0.5f) { ux = sse_min(ux * 2, kOneMinusEps); w = cosine_hemisphere(ux, u2y); }
+        else { ux = sse_min((ux - 0.5f) * 2, kOneMinusEps); w = cosine_hemisphere(ux, u2y); w.z *= -1; }
+        e.pdf_dir = 0.5f * (fabsf(w.z) * kInvPi);
+    } else {
+        w = cosine_hemisphere(u2x, u2y);
+        e.pdf_dir = w.z * kInvPi;
+    }
+    F3 v1, v2;
+    coordinate_system(lp.n, &v1, &v2);
+    w = add3(add3(scale3(v1, w.x), scale3(v2, w.y)), scale3(lp.n, w.z));
+    e.Le = light_L(L, lp.n, w);
+    e.o = offset_ray_origin(lp.p, lp.perr, lp.n, w);
+    e.d = w;
+    e.n = lp.n;
+    return e;
+}
+
 }  // namespace tkd

@@ -88,6 +88,26 @@ class Context:
         check(self.lib, self.lib.tkhip_camera_rays(self.h, n, _fp(raster), _fp(org), _fp(d)), "tkhip_camera_rays")
         return org, d
 
+    def sample_f(self, material, mode, wo, nrm, u):
+        """Material::sample_f for n samples on one TkMaterial (mode 0 radiance, 1 importance)."""
+        wo, nrm, u = _f32(wo), _f32(nrm), _f32(u)
+        n = wo.shape[0]
+        wi = np.empty((n, 3), np.float32)
+        f = np.empty((n, 3), np.float32)
+        pdf = np.empty(n, np.float32)
+        check(self.lib, self.lib.tkhip_sample_f(self.h, C.byref(material), mode, n, _fp(wo), _fp(nrm), _fp(u), _fp(wi), _fp(f),
+                                                _fp(pdf)), "tkhip_sample_f")
+        return wi, f, pdf
+
+    def sample_le(self, light, u1, u2, upick):
+        """AreaLight::sample_Le on a light of the scene: (origin, direction, normal, Le, pdf_pos, pdf_dir)."""
+        u1, u2, upick = _f32(u1), _f32(u2), _f32(upick)
+        n = upick.shape[0]
+        out = [np.empty((n, 3), np.float32) for _ in range(4)] + [np.empty(n, np.float32) for _ in range(2)]
+        check(self.lib, self.lib.tkhip_sample_le(self.h, light, n, _fp(u1), _fp(u2), _fp(upick), *[_fp(o) for o in out]),
+              "tkhip_sample_le")
+        return tuple(out)
+
     def radical_inverse(self, dim, index):
         dim = np.ascontiguousarray(dim, np.int32)
         index = np.ascontiguousarray(index, np.uint64)

@@ -7,6 +7,7 @@ Hand-derived known answers live in the tests themselves.
 
     python tests/golden/make_golden.py
 """
+import ctypes as C
 import os
 import sys
 
@@ -16,10 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from oracle import oracle_py as O  # noqa: E402
+from pathtracer_amd import _abi  # noqa: E402
 from pathtracer_amd.scene import Scene, asset_scene  # noqa: E402
 from tests.conftest import make_photons, make_queries  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+L = O.lib()
 
 
 def main():
@@ -114,6 +117,67 @@ def main():
                             nrm=nrm, perr=perr, org2=o2, dir2=d2, prim2=prim2, t2=t2, p2=p2, nrm2=n2, perr2=e2)
         osc.close()
 
+    materials_and_lights()
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def sample_f(material, mode, wo, nrm, u):
+    n = len(wo)
+    wi = np.zeros((n, 3), np.float32); f = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+    L.orc_sample_f(C.byref(material), mode, n, O.fp(wo), O.fp(nrm), O.fp(u), O.fp(wi), O.fp(f), O.fp(pdf))
+    return wi, f, pdf
+
+
+def sample_le(osc, light, u1, u2, upick):
+    n = len(upick)
+    out = [np.zeros((n, 3), np.float32) for _ in range(4)] + [np.zeros(n, np.float32) for _ in range(2)]
+    L.orc_sample_le(osc.h, light, n, O.fp(u1), O.fp(u2), O.fp(upick), *[O.fp(o) for o in out])
+    return out
+
+
+def materials_and_lights():
+    """F7 / F9: Material::sample_f of the three materials in both transport modes, and AreaLight::sample_Le of
+    the Cornell light.  Own random stream, so that the fixtures above do not move."""
+    rng = np.random.default_rng(20261111)
+    sc = Scene.load(asset_scene("cornell_sphere.scene"))
+    n = 600
+    nrm = _unit(rng.normal(size=(n, 3)))
+    wo = _unit(rng.normal(size=(n, 3)))
+    wo[::7] = _unit(nrm[::7] + 0.05 * rng.normal(size=nrm[::7].shape))     # near-normal incidence
+    wo[3::11] = _unit(np.cross(nrm[3::11], wo[3::11]) + 0.01 * nrm[3::11])  # grazing
+    u = rng.random((n, 2)).astype(np.float32)
+    u[:3] = [[0, 0], [0.999999, 0.999999], [0.5, 0.5]]
+    out = {"wo": wo, "nrm": nrm, "u": u}
+    kinds = {_abi.TK_DIFFUSE: "diffuse", _abi.TK_MIRROR: "mirror", _abi.TK_GLASS: "glass"}
+    seen = set()
+    for i in range(sc.n_materials):
+        m = sc.materials[i]
+        if m.type in seen:
+            continue
+        seen.add(m.type)
+        name = kinds[m.type]
+        out[name + "_material"] = np.frombuffer(bytes(m), np.uint8).copy()
+        for mode in (0, 1):
+            wi, f, pdf = sample_f(m, mode, wo, nrm, u)
+            out[f"{name}_wi_{mode}"] = wi; out[f"{name}_f_{mode}"] = f; out[f"{name}_pdf_{mode}"] = pdf
+    assert seen == set(kinds)
+    np.savez_compressed(os.path.join(OUT, "sample_f.npz"), **out)
+    osc = O.OracleScene(sc, 64, 64)
+    m = 800
+    u1 = rng.random((m, 2)).astype(np.float32); u2 = rng.random((m, 2)).astype(np.float32)
+    upick = rng.random(m).astype(np.float32)
+    u1[:2] = [[0, 0], [0.999999, 0.999999]]; upick[:2] = [0, 0.999999]
+    org, d, nl, le, pp, pd = sample_le(osc, 0, u1, u2, upick)
+    np.savez_compressed(os.path.join(OUT, "sample_le_cornell_sphere.npz"), u1=u1, u2=u2, upick=upick, org=org, dir=d, nrm=nl,
+                        le=le, pdf_pos=pp, pdf_dir=pd)
+    osc.close()
+
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "materials":
+        materials_and_lights()
+    else:
+        main()

@@ -385,3 +385,77 @@ def test_iterations_shrink_radius_and_accumulate(sphere_scene):
     assert nr == 4 and sg > 0 and sc_ > 0
     r.close()
     osc.close()
+
+
+# ------------------------------------------------------------------ materials and light emission (F7 / F9)
+def _material(raw):
+    return _abi.TkMaterial.from_buffer_copy(bytes(raw))
+
+
+def test_sample_f_golden_and_known_answers():
+    import ctypes as C
+    g = golden("sample_f.npz")
+    wo, nrm, u = g["wo"], g["nrm"], g["u"]
+    n = len(wo)
+    for name in ("diffuse", "mirror", "glass"):
+        m = _material(g[name + "_material"])
+        for mode in (0, 1):
+            wi = np.zeros((n, 3), np.float32); f = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+            L.orc_sample_f(C.byref(m), mode, n, O.fp(wo), O.fp(nrm), O.fp(u), O.fp(wi), O.fp(f), O.fp(pdf))
+            assert np.array_equal(wi, g[f"{name}_wi_{mode}"]) and np.array_equal(f, g[f"{name}_f_{mode}"])
+            assert np.array_equal(pdf, g[f"{name}_pdf_{mode}"])
+    cos_o = (wo * nrm).sum(1)
+    # diffuse (src/core/Material.cpp:22-47): wi in the +N hemisphere, pdf = cos/pi and f = R/pi where wo is on that side, else 0
+    wi, f, pdf = g["diffuse_wi_0"], g["diffuse_f_0"], g["diffuse_pdf_0"]
+    cos_i = (wi * nrm).sum(1)
+    front = cos_o > 1e-4
+    assert (cos_i > -1e-6).all()
+    assert np.allclose(pdf[front], cos_i[front] / np.pi, rtol=2e-5, atol=1e-7)
+    R = np.array(_material(g["diffuse_material"]).R[:], np.float32)
+    assert np.allclose(f[front], R / np.pi, rtol=1e-6)
+    assert (pdf[cos_o < -1e-4] == 0).all() and (f[cos_o < -1e-4] == 0).all()
+    # mirror (:83-95): wi = reflect(wo, N), pdf 1, f = R / |cos|
+    wi, f, pdf = g["mirror_wi_0"], g["mirror_f_0"], g["mirror_pdf_0"]
+    refl = -wo + 2 * cos_o[:, None] * nrm
+    assert np.allclose(wi, refl, atol=2e-6) and (pdf == 1).all()
+    Rm = np.array(_material(g["mirror_material"]).R[:], np.float32)
+    assert np.allclose(f * np.abs((wi * nrm).sum(1))[:, None], Rm, rtol=2e-5)
+    # glass (:49-81): reflection with probability Fr (pdf Fr), refraction otherwise (pdf 1 - Fr); the radiance
+    # mode scales refraction by (eta_i / eta_t)^2, the importance mode does not
+    wi0, f0, p0 = g["glass_wi_0"], g["glass_f_0"], g["glass_pdf_0"]
+    wi1, f1, p1 = g["glass_wi_1"], g["glass_f_1"], g["glass_pdf_1"]
+    assert np.array_equal(wi0, wi1) and np.array_equal(p0, p1) and ((p0 >= 0) & (p0 <= 1)).all()
+    reflected = np.sign((wi0 * nrm).sum(1)) == np.sign(cos_o)
+    assert reflected.any() and (~reflected).any()
+    assert np.array_equal(f0[reflected], f1[reflected])
+    gm = _material(g["glass_material"])
+    refr = ~reflected & (p0 > 0)
+    entering = cos_o[refr] > 0
+    ratio = f0[refr][:, 0] / f1[refr][:, 0]
+    eta = gm.etaB / gm.etaA
+    assert np.allclose(ratio[entering], 1 / eta ** 2, rtol=1e-5) and np.allclose(ratio[~entering], eta ** 2, rtol=1e-5)
+
+
+def test_sample_le_golden_and_known_answers(sphere_scene):
+    g = golden("sample_le_cornell_sphere.npz")
+    osc = O.OracleScene(sphere_scene, 64, 64)
+    n = len(g["upick"])
+    out = [np.zeros((n, 3), np.float32) for _ in range(4)] + [np.zeros(n, np.float32) for _ in range(2)]
+    L.orc_sample_le(osc.h, 0, n, O.fp(g["u1"]), O.fp(g["u2"]), O.fp(g["upick"]), *[O.fp(o) for o in out])
+    for got, key in zip(out, ("org", "dir", "nrm", "le", "pdf_pos", "pdf_dir")):
+        assert np.array_equal(got, g[key]), key
+    org, d, nl, le, pp, pd = out
+    light = sphere_scene.lights[0]
+    ob = sphere_scene.objects[light.object]
+    tris = sphere_scene.triangles_np()[ob.first:ob.first + ob.count]
+    area = 0.5 * np.linalg.norm(np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]), axis=1)
+    # two equal triangles: picking one (1/2) and a point on it (1/area) gives 1 / total area (src/Triangle.cpp:190-197)
+    assert np.allclose(pp, 1.0 / area.sum(), rtol=1e-5)
+    cos = (d * nl).sum(1)
+    assert (cos >= 0).all() and np.allclose(pd, cos / np.pi, rtol=3e-5, atol=1e-7)          # src/Light.cpp:63-66
+    assert np.allclose(np.linalg.norm(d, axis=1), 1, atol=1e-5)
+    assert np.allclose(le[cos > 0], np.array(light.Le[:], np.float32))
+    # the ray starts on the light (offset by a few ulps along the normal): inside the bounds of its triangles
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    assert ((org >= lo - 1e-4) & (org <= hi + 1e-4)).all()
+    osc.close()
