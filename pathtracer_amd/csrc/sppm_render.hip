@@ -32,6 +32,8 @@
 
 namespace tkd {
 
+constexpr int kCounterBytes = 64;
+
 enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */, C_QD = 12 };
 
 // Everything one concurrently running pass needs: its stream, path state,
@@ -43,7 +45,8 @@ struct Lane {
     hipStream_t stream = nullptr;
     DevBuf counters;
     DevBuf q_o, q_d, q_w;            // path records between the two stages of a pass
-    int32_t* h_counters = nullptr;   // pinned host copy of the first counters
+    int32_t* h_counters = nullptr;   // pinned host copy of the counters
+    int64_t queued_last = -1, batch_last = 0;   // paths the first stage of the last batch queued, and its size
     DevBuf stage_pos, stage_pow, rec_count, rec_offset, prim_temp;
     void release() {
         DevBuf* bufs[] = {&counters, &q_o, &q_d, &q_w, &stage_pos, &stage_pow, &rec_count, &rec_offset, &prim_temp};
@@ -686,7 +689,13 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
     TK_HIP(hipMemsetAsync(&counters[C_QD], 0, 4, stream));
     k_photon_first<KIND><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
-    const int waves = (int)std::min<int64_t>(divup(B, kPathBlock), s->path_waves[KIND]);
+    // Second-stage grid: enough waves for two path loads each of what the queue held last time (the
+    // long paths need the refill to keep their waves full), at most what fits the GPU.  The photon
+    // passes share the GPU with the camera pass, whose queue is the longest: waves of a light-path
+    // kernel that would find nothing to refill from are better left to it.
+    int64_t want = divup(B, kPathBlock);
+    if (ln.queued_last >= 0) want = std::max<int64_t>(divup(ln.queued_last * B / std::max<int64_t>(ln.batch_last, 1), 2 * kPathBlock), 256);
+    const int waves = (int)std::min<int64_t>(want, s->path_waves[KIND]);
     k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
@@ -695,7 +704,7 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
                                                         quota, s->loc_pos[KIND].as<float>(), s->loc_pow[KIND].as<float>(),
                                                         s->loc_dir[KIND].as<uint16_t>(), counters);
     TK_LAUNCH_CHECK();
-    TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 6 * 4, hipMemcpyDeviceToHost, stream));
+    TK_HIP(hipMemcpyAsync(ln.h_counters, counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
     *B_out = B;
     return TKHIP_OK;
 }
@@ -723,6 +732,8 @@ static int photon_pass_finish(tkhip_ctx* ctx, int64_t B) {
     while (B > 0) {
         TK_HIP(hipStreamSynchronize(ln.stream));
         const int64_t need = quota - stored;
+        ln.queued_last = (int64_t)ln.h_counters[C_QB] + ln.h_counters[C_QD];
+        ln.batch_last = B;
         const int64_t total = ln.h_counters[C_TOTAL];
         const int64_t got = std::min<int64_t>(total, need);
         const int64_t used = total >= need ? ln.h_counters[C_USED] : B;
