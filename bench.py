@@ -103,6 +103,8 @@ def main():
                          "quads (2236 gives the 10 M-triangle configuration)")
     ap.add_argument("--photons", type=int, nargs=2, default=None, metavar=("GLOBAL", "CAUSTIC"),
                     help="override the photon map sizes of the scene")
+    ap.add_argument("--tree", choices=("curve", "median"), default="curve",
+                    help="photon tree layout: one sort along a Hilbert curve (default) or median splits level by level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses N > 1 on fewer GPUs")
@@ -146,6 +148,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     lib, ctx_h = backend.lib, backend.h
+    _abi.check(lib, lib.tkhip_sppm_set_tree(ctx_h, 1 if args.tree == "median" else 0), "tkhip_sppm_set_tree")
 
     def gather_totals(reset):
         t = _abi.TkGatherTotals()
@@ -229,7 +232,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H}, {param.globalSize} global + {param.causticSize} caustic photons/iter, "
                                    f"k={k_g}/{k_c}, depth {max_depth}, 1 ray/pixel",
-                       "parallelism": f"photon paths + pixel rows over {world} GPU(s), photon all-gather"},
+                       "parallelism": f"photon paths + pixel rows over {world} GPU(s), photon all-gather",
+                       "photon_tree": args.tree},
             "mrays_per_s": rays / (ms_step * 1e-3) / 1e6,
             "gathers_per_s": (ng + nc) / (ms_step * 1e-3),
             "photon_paths_per_s": (gpaths + cpaths) / (ms_step * 1e-3),

@@ -101,6 +101,7 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_set_map_photons": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_int64]),
     "tkhip_sppm_build_maps": (C.c_int, [C.c_void_p, C.POINTER(TkIterStats)]),
+    "tkhip_sppm_set_tree": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_camera_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_gather_totals": (C.c_int, [C.c_void_p, C.POINTER(TkGatherTotals), C.c_int]),
     "tkhip_sppm_camera_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
@@ -113,6 +114,7 @@ TKHIP_SYMBOLS = {
     "tkhip_map_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "tkhip_map_destroy": (None, [C.c_void_p]),
     "tkhip_map_store": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_uint8_p, c_uint8_p, C.c_int64]),
+    "tkhip_map_set_tree": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_map_build": (C.c_int, [C.c_void_p]),
     "tkhip_map_tree_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "tkhip_map_gather": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p,

@@ -48,7 +48,8 @@ struct tkhip_map {
     bool built = false;
     int nl = 0, depth = 0;
     tkd::DevBuf in_pos, in_pow, in_dir;            // storage order: float3, float3, u16
-    tkd::DevBuf pos4, pow4, node_box;
+    tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
+    int tree_mode = 0;              // 0: one sort along a Hilbert curve; 1: median splits, one sort per level
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
     float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)

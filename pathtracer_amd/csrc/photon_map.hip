@@ -138,6 +138,56 @@ __global__ void k_photon_curve(const float* pos, int64_t n, const uint32_t* box6
     vals[i] = (uint32_t)i;
 }
 
+// ---- the median-split build (PhotonMap::balance, src/tracer/Photonmap.cpp:132-179, level by level):
+// every level sorts the photons by (node, coordinate on the node's split axis); a node's photons are
+// then contiguous and its median is the first photon of its right half.  The split axis is the
+// widest axis of the node's box, the parent's box clipped at the split planes above
+// (Bounds3::maxExtent, src/Bounds3.hpp:32-41; :149-152, :167-170).
+__global__ void k_iota(uint32_t* a, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+// clip_box: 6 floats per heap node (min xyz, max xyz); node 1 is the root.
+__global__ void k_root_clip(const uint32_t* box6, float* clip_box) {
+    if (threadIdx.x < 6) clip_box[6 + threadIdx.x] = ord2f(box6[threadIdx.x]);
+}
+__global__ void k_level_axis(const float* clip_box, int32_t* node_axis, int level) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int count = 1 << level;
+    if (j >= count) return;
+    int node = count + j;
+    const float* b = clip_box + 6 * (int64_t)node;
+    float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    node_axis[node] = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
+}
+__global__ void k_level_keys(const float* pos, const uint32_t* idx, const int32_t* node_axis, uint64_t* keys,
+                             int64_t n, int nl, int depth, int level) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int leaf = (int)(((i + 1) * nl - 1) / n);   // the leaf position i falls into: inverse of leaf_start
+    const int j = leaf >> (depth - level);
+    const int axis = node_axis[(1 << level) + j];
+    const float v = pos[3 * (int64_t)idx[i] + axis];
+    keys[i] = ((uint64_t)(uint32_t)j << 32) | f2ord(v);
+}
+__global__ void k_level_split(const float* pos, const uint32_t* idx, float* clip_box, const int32_t* node_axis,
+                              int64_t n, int depth, int level) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int count = 1 << level;
+    if (j >= count) return;
+    int node = count + j;
+    int axis = node_axis[node];
+    int mid_leaf = (2 * j + 1) << (depth - level - 1);
+    int64_t mid = leaf_start(mid_leaf, n, depth);
+    float split = pos[3 * (int64_t)idx[mid] + axis];
+    const float* b = clip_box + 6 * (int64_t)node;
+    float* l = clip_box + 6 * (int64_t)(2 * node);
+    float* r = clip_box + 6 * (int64_t)(2 * node + 1);
+    for (int a = 0; a < 6; ++a) { l[a] = b[a]; r[a] = b[a]; }
+    l[3 + axis] = split;
+    r[axis] = split;
+}
+
 __global__ void k_permute(const float* pos, const float* pow, const uint16_t* dir, const uint32_t* idx,
                           float4* pos4, float4* pow4, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -681,7 +731,7 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
 
 void map_destroy(tkhip_map* m) {
     if (!m) return;
-    DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
+    DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->node_axis, &m->clip_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
                       &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters, &m->prim_temp};
     for (DevBuf* b : bufs) b->release();
     m->totals.release();
@@ -734,10 +784,38 @@ int map_build(tkhip_map* m) {
     uint32_t* box6 = m->root_box.as<uint32_t>();
     k_bounds_init<<<1, 64, 0, s>>>(box6);
     k_bounds<<<std::min(divup(n, B * 8), 256), B, 0, s>>>(pos, n, box6);
-    k_photon_curve<<<divup(n, B), B, 0, s>>>(pos, n, box6, m->key_a.as<uint32_t>(), m->idx_b.as<uint32_t>());
-    TK_LAUNCH_CHECK();
-    TK_TRY(sort_pairs_u32(s, m->prim_temp, m->key_a.as<uint32_t>(), m->key_b.as<uint32_t>(), m->idx_b.as<uint32_t>(),
-                          m->idx_a.as<uint32_t>(), (size_t)n, 30));   // idx_a: the leaf order
+    if (m->tree_mode == 1 && depth > 0) {
+        // median splits, one sort per level: the layout PhotonMap::balance produces (with the widest
+        // axis the reference meant to take); some 6 launches per level
+        TK_TRY(m->key_a.ensure((size_t)n * 8));
+        TK_TRY(m->key_b.ensure((size_t)n * 8));
+        TK_TRY(m->node_axis.ensure((size_t)nl * 2 * 4));
+        TK_TRY(m->clip_box.ensure((size_t)nl * 2 * 24));
+        uint32_t* idx = m->idx_a.as<uint32_t>();
+        uint32_t* idx_alt = m->idx_b.as<uint32_t>();
+        k_iota<<<divup(n, B), B, 0, s>>>(idx, n);
+        k_root_clip<<<1, 64, 0, s>>>(box6, m->clip_box.as<float>());
+        TK_LAUNCH_CHECK();
+        for (int level = 0; level < depth; ++level) {
+            const int nodes = 1 << level;
+            k_level_axis<<<divup(nodes, B), B, 0, s>>>(m->clip_box.as<float>(), m->node_axis.as<int32_t>(), level);
+            k_level_keys<<<divup(n, B), B, 0, s>>>(pos, idx, m->node_axis.as<int32_t>(), m->key_a.as<uint64_t>(), n, nl,
+                                                   depth, level);
+            TK_LAUNCH_CHECK();
+            TK_TRY(sort_pairs_u64(s, m->prim_temp, m->key_a.as<uint64_t>(), m->key_b.as<uint64_t>(), idx, idx_alt, (size_t)n,
+                                  32 + level));
+            std::swap(idx, idx_alt);
+            k_level_split<<<divup(nodes, B), B, 0, s>>>(pos, idx, m->clip_box.as<float>(), m->node_axis.as<int32_t>(), n,
+                                                        depth, level);
+            TK_LAUNCH_CHECK();
+        }
+        if (idx != m->idx_a.as<uint32_t>()) std::swap(m->idx_a, m->idx_b);   // idx_a: the leaf order
+    } else {
+        k_photon_curve<<<divup(n, B), B, 0, s>>>(pos, n, box6, m->key_a.as<uint32_t>(), m->idx_b.as<uint32_t>());
+        TK_LAUNCH_CHECK();
+        TK_TRY(sort_pairs_u32(s, m->prim_temp, m->key_a.as<uint32_t>(), m->key_b.as<uint32_t>(), m->idx_b.as<uint32_t>(),
+                              m->idx_a.as<uint32_t>(), (size_t)n, 30));   // idx_a: the leaf order
+    }
     k_permute<<<divup(n, B), B, 0, s>>>(pos, m->in_pow.as<float>(), m->in_dir.as<uint16_t>(), m->idx_a.as<uint32_t>(),
                                         m->pos4.as<float4>(), m->pow4.as<float4>(), n);
     k_leaf_boxes<<<divup(nl, 64), 64, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl, depth);
@@ -918,6 +996,14 @@ int tkhip_map_store(tkhip_map* m, const float* pos, const float* power, const ui
     TK_LAUNCH_CHECK();
     TK_HIP(hipStreamSynchronize(s));
     m->n += n;
+    m->built = false;
+    return TKHIP_OK;
+}
+
+int tkhip_map_set_tree(tkhip_map* m, int mode) {
+    TK_REQUIRE(m != nullptr, TKHIP_E_ARG, "tkhip_map_set_tree: null map");
+    TK_REQUIRE(mode == 0 || mode == 1, TKHIP_E_ARG, "tkhip_map_set_tree: mode must be 0 (curve order) or 1 (median splits)");
+    m->tree_mode = mode;
     m->built = false;
     return TKHIP_OK;
 }

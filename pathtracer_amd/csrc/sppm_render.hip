@@ -1101,6 +1101,12 @@ int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* st) {
     return TKHIP_OK;
 }
 
+int tkhip_sppm_set_tree(tkhip_ctx* ctx, int mode) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_set_tree");
+    TK_TRY(tkhip_map_set_tree(ctx->sppm->map[0], mode));
+    return tkhip_map_set_tree(ctx->sppm->map[1], mode);
+}
+
 int tkhip_sppm_camera_begin(tkhip_ctx* ctx, int iter) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_camera_begin");
     SppmState* s = ctx->sppm;

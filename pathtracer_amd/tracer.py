@@ -153,6 +153,10 @@ class PhotonMap:
         check(self.lib, self.lib.tkhip_map_store(self.h, _fp(pos), _fp(power), _bp(theta), _bp(phi), pos.shape[0]),
               "tkhip_map_store")
 
+    def set_tree(self, mode):
+        """0: one sort along a Hilbert curve (default); 1: median splits, one sort per level."""
+        check(self.lib, self.lib.tkhip_map_set_tree(self.h, mode), "tkhip_map_set_tree")
+
     def build(self):
         check(self.lib, self.lib.tkhip_map_build(self.h), "tkhip_map_build")
 

@@ -125,9 +125,10 @@ def test_ray_hits_match_oracle_on_the_dragon(gpu_ctx, dragon_scene):
 
 
 # ------------------------------------------------------------------ kNN gather
-def _gpu_map(ctx, g_or_arrays, k):
+def _gpu_map(ctx, g_or_arrays, k, tree=0):
     pos, power, th, ph = g_or_arrays
     m = PhotonMap(ctx, len(pos), k)
+    m.set_tree(tree)
     m.store(pos, power, th, ph)
     m.build()
     return m
@@ -135,9 +136,11 @@ def _gpu_map(ctx, g_or_arrays, k):
 
 @pytest.mark.parametrize("name", ["knn_surface.npz", "knn_small_k50.npz", "knn_ties.npz"])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_knn_matches_golden(gpu_ctx, name, mode):
+@pytest.mark.parametrize("tree", [0, 1])
+def test_knn_matches_golden(gpu_ctx, name, mode, tree):
+    """Both gather kernels on both tree layouts (Hilbert order, median splits): the same neighbour sets."""
     g = golden(name)
-    m = _gpu_map(gpu_ctx, (g["pos"], g["power"], g["theta"], g["phi"]), int(g["k"]))
+    m = _gpu_map(gpu_ctx, (g["pos"], g["power"], g["theta"], g["phi"]), int(g["k"]), tree)
     flux, found, r2o, idx = m.gather(g["qp"], g["qn"], g["qwo"], g["qR"], g["r2"], mode=mode)
     assert (found == g["found"]).all()
     assert (idx == g["idx"]).all()            # neighbour index sets, ties broken by photon index
@@ -151,18 +154,24 @@ def test_knn_matches_oracle_random(gpu_ctx, n, k, nq):
     rng = np.random.default_rng(n + k)
     pos, power, th, ph = make_photons(rng, n)
     qp, qn, qwo, qR, r2 = make_queries(rng, nq, radius2=(0.08, 0.5, 1e-3, 30.0))
-    gm = _gpu_map(gpu_ctx, (pos, power, th, ph), k)
-    nl, cap, depth, perm = gm.tree_info(n)
-    assert sorted(perm.tolist()) == list(range(n)) and nl * cap >= n and nl == 1 << depth
     om = O.OracleMap(n, k)
     om.store(pos, power, th, ph)
     om.build(1)
     of, ofound, or2, oidx = om.gather(qp, qn, qwo, qR, r2)
-    for mode in (0, 1):
-        gf, gfound, gr2, gidx = gm.gather(qp, qn, qwo, qR, r2, mode=mode)
-        assert (gfound == ofound).all() and (gidx == oidx).all() and (gr2 == or2).all()
-        _flux_close(gf, of)
-    gm.close()
+    for tree in (0, 1):
+        gm = _gpu_map(gpu_ctx, (pos, power, th, ph), k, tree)
+        nl, cap, depth, perm = gm.tree_info(n)
+        assert sorted(perm.tolist()) == list(range(n)) and nl * cap >= n and nl == 1 << depth
+        if tree == 1 and depth > 0:
+            # median split of the root on the widest axis: the left half lies below the right half on it
+            axis = int(np.argmax(pos.max(0) - pos.min(0)))
+            half = (nl // 2) * n // nl
+            assert pos[perm[:half], axis].max() <= pos[perm[half:], axis].min()
+        for mode in (0, 1):
+            gf, gfound, gr2, gidx = gm.gather(qp, qn, qwo, qR, r2, mode=mode)
+            assert (gfound == ofound).all() and (gidx == oidx).all() and (gr2 == or2).all()
+            _flux_close(gf, of)
+        gm.close()
     om.close()
 
 
