@@ -378,13 +378,14 @@ TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay
 
 // Appends the photons of leaf node `node` that lie inside the current bound to
 // the candidate buffer.  Lanes [lane0, lane0+32) of the wave serve this leaf.
-static_assert(kLeafCap <= 32, "two leaves are served by the two halves of a wave");
+static_assert(64 % kLeafCap == 0, "a step of a gather kernel serves 64 / kLeafCap leaves, one photon per lane");
+constexpr int kLeavesPerStep = 64 / kLeafCap;
 
 template <int EPL>
 __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, const int32_t* list,
                                                      const int32_t* list_count, int64_t nq, GatherOut out) {
     constexpr int CAP = 64 * EPL;
-    constexpr int FCAP = 256;            // frontier entries of the level-by-level descent
+    constexpr int FCAP = 128 * kLeavesPerStep;   // frontier entries of the level-by-level descent
     __shared__ unsigned long long s_keys[4][CAP];
     __shared__ uint32_t s_pay[4][CAP];
     __shared__ int s_node[4][64];
@@ -410,15 +411,15 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         int count = 0;
         const bool searchable = mv.n > 0 && Q.r2 > 0.f;
 
-        // The photons of one or two leaves against the bound; survivors join the buffer.
-        auto take_leaves = [&](int node_a, int node_b) {
-            const int half = lane >> 5, ph = lane & 31;
-            const int node = half ? node_b : node_a;
+        // The photons of up to kLeavesPerStep leaves (nodes[0 .. count), wave-uniform) against the
+        // bound, one photon per lane; survivors join the buffer.
+        auto take_leaves = [&](const int* nodes, int count_nodes) {
+            const int slot = lane / kLeafCap, ph = lane % kLeafCap;
             bool acc = false;
             unsigned long long key = 0;
             uint32_t at = 0;
-            if (node > 0) {
-                const int leaf = node - mv.nl;
+            if (slot < count_nodes) {
+                const int leaf = nodes[slot] - mv.nl;
                 const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
                 if (ph < (int)(e0 - s0)) {
                     at = (uint32_t)(s0 + ph);
@@ -475,10 +476,8 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                 fcount = ncount;
             }
             if (fits) {
-                for (int i = 0; i < fcount; i += 2) {
-                    const int na = front[cur][i], nb = i + 1 < fcount ? front[cur][i + 1] : 0;
-                    take_leaves(uniform_i(na), uniform_i(nb));
-                }
+                for (int i = 0; i < fcount; i += kLeavesPerStep)
+                    take_leaves(&front[cur][i], fcount - i < kLeavesPerStep ? fcount - i : kLeavesPerStep);
                 done = true;
             }
         }
@@ -504,7 +503,8 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                     if (df < bound_d2) { if (lane == 0) { st_node[sp] = fn; st_d2[sp] = df; } ++sp; }
                     if (dn < bound_d2) { if (lane == 0) { st_node[sp] = nn; st_d2[sp] = dn; } ++sp; }
                 } else {
-                    take_leaves(node, 0);
+                    if (lane == 0) st_node[63] = node;    // the stack never reaches its last entry
+                    take_leaves(&st_node[63], 1);
                 }
             }
         }
@@ -552,12 +552,12 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
 // A query that meets fewer than k photons inside its radius is finished here
 // (no selection is needed: found < k keeps them all and leaves the radius
 // unchanged); the rest go to the per-query kernel.
-constexpr int kMaxGroupLeaves = 48;
+constexpr int kMaxGroupLeaves = 24 * kLeavesPerStep;
 
 template <bool WANT_IDX>
 __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, const uint32_t* order, int64_t nq,
                                                       GatherOut out, int32_t* overflow, int32_t* overflow_count) {
-    constexpr int FCAP = 128;
+    constexpr int FCAP = 64 * kLeavesPerStep;
     __shared__ float s_tab[1024];
     __shared__ float4 s_pos[4][64];   // x, y, z, original index
     __shared__ float4 s_dir[4][64];   // wi, power.r
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, ph = lane & 31;
+    const int leaf_slot = lane / kLeafCap, ph = lane % kLeafCap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int k = mv.k;
     const int64_t ngroups = (nq + 63) >> 6;
@@ -628,36 +628,34 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
             // A wave that would have to stream far more leaves than its neighbours (its queries straddle
             // two surfaces, or one of them still has a large radius) would hold up the whole launch.
             if (fcount > kMaxGroupLeaves) spread = true;
-            // 2. the photons of those leaves, two leaves per step, next step's loads in flight
+            // 2. the photons of those leaves, a step at a time, next step's loads in flight
             if (!spread && fcount > 0) {
-                auto fetch = [&](int i, float4* pp, float4* pw, int* na, int* nb) {
-                    const int node_a = uniform_i(front[cur][i]);
-                    const int node_b = i + 1 < fcount ? uniform_i(front[cur][i + 1]) : 0;
-                    const int64_t sa = leaf_start(node_a - mv.nl, mv.n, mv.depth), ea = leaf_start(node_a - mv.nl + 1, mv.n, mv.depth);
-                    int64_t sb = 0, eb = 0;
-                    if (node_b) { sb = leaf_start(node_b - mv.nl, mv.n, mv.depth); eb = leaf_start(node_b - mv.nl + 1, mv.n, mv.depth); }
-                    *na = (int)(ea - sa);
-                    *nb = (int)(eb - sb);
-                    const int64_t at = half ? sb + ph : sa + ph;
-                    const bool has = ph < (half ? *nb : *na);
-                    if (has) { *pp = mv.pos4[at]; *pw = mv.pow4[at]; }
+                // a step serves kLeavesPerStep leaves, one photon per lane (lane = leaf_slot * kLeafCap + photon)
+                auto fetch = [&](int i, float4* pp, float4* pw) {
+                    bool has = false;
+                    if (i + leaf_slot < fcount) {
+                        const int leaf = front[cur][i + leaf_slot] - mv.nl;
+                        const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
+                        has = ph < (int)(e0 - s0);
+                        if (has) { *pp = mv.pos4[s0 + ph]; *pw = mv.pow4[s0 + ph]; }
+                    }
+                    return has;
                 };
                 float4 pp = make_float4(0, 0, 0, 0), pw = pp;
-                int na = 0, nb = 0;
-                fetch(0, &pp, &pw, &na, &nb);
-                for (int i = 0; i < fcount; i += 2) {
-                    const int ca = na, cb = nb;
+                bool has = fetch(0, &pp, &pw);
+                for (int i = 0; i < fcount; i += kLeavesPerStep) {
+                    const unsigned long long staged = __ballot(has);
+                    const int n_in = __popcll(staged);
                     __builtin_amdgcn_wave_barrier();      // the previous step has been read by every lane
-                    if (ph < (half ? cb : ca)) {
-                        const int at = half ? ca + ph : ph;
+                    if (has) {
+                        const int at = __popcll(staged & lt_mask);
                         F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
                         s_pos[wave][at] = pp;
                         s_dir[wave][at] = make_float4(wi.x, wi.y, wi.z, pw.x);
                         s_pow[wave][at] = make_float2(pw.y, pw.z);
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (i + 2 < fcount) fetch(i + 2, &pp, &pw, &na, &nb);
-                    const int n_in = ca + cb;
+                    has = i + kLeavesPerStep < fcount ? fetch(i + kLeavesPerStep, &pp, &pw) : false;
                     staged_sum += (unsigned long long)n_in;
 #pragma unroll 4
                     for (int c = 0; c < n_in; ++c) {
