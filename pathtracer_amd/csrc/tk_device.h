@@ -171,7 +171,8 @@ TKD int permutation_element(uint32_t i, uint32_t l, uint32_t p) {   // src/TkMat
         i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2;
         i *= 0x9e501cc3u; i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
     } while (i >= l);
-    return (int)((i + p) % l);
+    // (i + p) % l, without the division when l is a power of two (then l - 1 == w)
+    return (int)((l & w) == 0 ? ((i + p) & w) : ((i + p) % l));
 }
 
 // StratifiedSampler of the thread that calls render() (seed 0), jittered
@@ -193,7 +194,9 @@ TKD void sampler_get2d(Sampler& s, float* ox, float* oy) {
     int stratum = permutation_element((uint32_t)s.sample_idx, (uint32_t)s.spp, (uint32_t)hash);
     int d = s.dim;
     s.dim += 2;
-    int x = stratum % s.xs, y = stratum / s.xs;
+    int x, y;
+    if ((s.xs & (s.xs - 1)) == 0) { x = stratum & (s.xs - 1); y = stratum >> (__ffs(s.xs) - 1); }   // no division for 2^n strata
+    else { x = stratum % s.xs; y = stratum / s.xs; }
     float dx = rng_u01(s.rng_seed, s.rng_pixel, s.rng_iter, (uint32_t)(2 * d));
     float dy = rng_u01(s.rng_seed, s.rng_pixel, s.rng_iter, (uint32_t)(2 * d + 1));
     *ox = (x + dx) / s.xs;
