@@ -307,7 +307,7 @@ TKD float box_dist2(const MapView& mv, int node, F3 p) {
 // neighbor_search (src/tracer/neighbor.cpp:31-83) restated for 64 lanes.
 
 template <int EPL>
-TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay, int* count_io, int k, int lane) {
+TKD unsigned long long wave_select_radix(unsigned long long* keys, uint32_t* pay, int* count_io, int k, int lane) {
     int count = *count_io;
     const int nchunk = (count + 63) >> 6;
     // k-th smallest high word (dist2 bits; non-negative floats order as integers)
@@ -376,6 +376,78 @@ TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay
     return wave_max_u64(kmax);
 }
 
+// The same cut, found faster in the common case: the keys are counted into 64
+// equal bins of dist2 over [0, limit_d2] (no key lies beyond), a scan of the
+// counts names the bin the k-th smallest key falls in, and the few keys of that
+// bin are ranked against each other.  bin(dist2) is monotone, so the cut is the
+// exact k-th smallest key.  More than 64 keys in that bin (many photons at one
+// distance): the radix select above takes over.
+//   hist: 64 ints, cand: 64 keys, both LDS of this wave.
+template <int EPL>
+TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay, int* count_io, int k, int lane,
+                                         float limit_d2, int* hist, unsigned long long* cand) {
+    const int count = *count_io;
+    const int nchunk = (count + 63) >> 6;
+    const float scale = 64.f / limit_d2;
+    auto bin_of = [&](unsigned long long key) {
+        const int b = (int)(__uint_as_float((uint32_t)(key >> 32)) * scale);
+        return b > 63 ? 63 : (b < 0 ? 0 : b);
+    };
+    hist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int e = ch * 64 + lane;
+        if (e < count) atomicAdd(&hist[bin_of(keys[e])], 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int mine = hist[lane];
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const unsigned long long reach = __ballot(incl >= k);
+    if (reach == 0ull) return wave_select_radix<EPL>(keys, pay, count_io, k, lane);   // count < k: not expected
+    const int bstar = __ffsll((long long)reach) - 1;
+    const int in_bin = __shfl(mine, bstar);
+    const int need = k - (__shfl(incl, bstar) - in_bin);
+    if (in_bin > 64) return wave_select_radix<EPL>(keys, pay, count_io, k, lane);
+    int nb = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int e = ch * 64 + lane;
+        unsigned long long key = 0;
+        bool t = false;
+        if (e < count) { key = keys[e]; t = bin_of(key) == bstar; }
+        const unsigned long long m = __ballot(t);
+        if (t) cand[nb + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        nb += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long my_key = lane < nb ? cand[lane] : ~0ull;
+    int rank = 0;
+    for (int j = 0; j < nb; ++j) rank += cand[j] < my_key ? 1 : 0;
+    const unsigned long long at = __ballot(lane < nb && rank == need - 1);
+    const int src = __ffsll((long long)at) - 1;
+    const unsigned long long cut = ((unsigned long long)(uint32_t)__shfl((int)(my_key >> 32), src) << 32) |
+                                   (unsigned long long)(uint32_t)__shfl((int)(uint32_t)my_key, src);
+    __builtin_amdgcn_wave_barrier();
+    // compact in place: chunk c only writes below what it has read
+    int w = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int e = ch * 64 + lane;
+        unsigned long long key = 0;
+        uint32_t p = 0;
+        bool keep = false;
+        if (e < count) { key = keys[e]; p = pay[e]; keep = key <= cut; }
+        const unsigned long long m = __ballot(keep);
+        const int dst = w + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) { keys[dst] = key; pay[dst] = p; }
+        w += __popcll(m);
+    }
+    *count_io = w;
+    return cut;
+}
+
 // Appends the photons of leaf node `node` that lie inside the current bound to
 // the candidate buffer.  Lanes [lane0, lane0+32) of the wave serve this leaf.
 static_assert(64 % kLeafCap == 0, "a step of a gather kernel serves 64 / kLeafCap leaves, one photon per lane");
@@ -392,6 +464,8 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
     __shared__ float s_nd2[4][64];
     __shared__ int s_front[4][2][FCAP];
     __shared__ float s_tab[1024];
+    __shared__ int s_hist[4][64];
+    __shared__ unsigned long long s_cand[4][64];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -435,7 +509,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                 if (acc) { keys[dst] = key; pay[dst] = at; }
                 count += __popcll(m);
                 if (count > CAP - 64) {
-                    bound = wave_select_prune<EPL>(keys, pay, &count, k, lane);
+                    bound = wave_select_prune<EPL>(keys, pay, &count, k, lane, bound_d2, s_hist[wave], s_cand[wave]);
                     // a photon exactly at the k-th distance can still win on its index
                     bound_d2 = __uint_as_float((uint32_t)(bound >> 32) + 1u);
                 }
@@ -511,7 +585,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         float r2ret = Q.r2;
         if (count >= k) {
             unsigned long long kmax;
-            if (count > k) kmax = wave_select_prune<EPL>(keys, pay, &count, k, lane);
+            if (count > k) kmax = wave_select_prune<EPL>(keys, pay, &count, k, lane, bound_d2, s_hist[wave], s_cand[wave]);
             else {
                 unsigned long long mine = 0;
                 for (int e = lane; e < count; e += 64) mine = keys[e] > mine ? keys[e] : mine;

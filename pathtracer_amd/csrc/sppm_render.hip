@@ -215,6 +215,15 @@ TKD int wave_fetch_work(int32_t* cursor, bool idle, int64_t n, bool* exhausted) 
     return (idle && mine < n) ? mine : -1;
 }
 
+// A wave runs as long as its slowest lane, and the more paths a wave walks at
+// once the longer that is.  When a queue holds fewer paths than the grid has
+// lanes, only the first lanes_in_use(n) lanes of every wave take paths: the
+// queue spreads over all the waves of the grid and is done sooner.
+TKD int lanes_in_use(int n) {
+    const int per_wave = (int)(((long long)n + gridDim.x - 1) / gridDim.x);
+    return per_wave < 1 ? 1 : (per_wave > 64 ? 64 : per_wave);
+}
+
 TKD void count_wave_rays(int32_t* counters, int nrays) {
     float wr = (float)nrays;
     for (int o2 = 32; o2 > 0; o2 >>= 1) wr += __shfl_xor(wr, o2);
@@ -262,12 +271,13 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
+    const bool takes = (int)(threadIdx.x & 63) < lanes_in_use(n);
     bool alive = false, exhausted = false;
     int slot = 0, bounce = 0, traced = 0;
     PhotonPath P{};
     while (true) {
-        if (!exhausted && !__all(alive)) {
-            const int got = wave_fetch_work(&counters[C_QA], !alive, n, &exhausted);
+        if (!exhausted && __any(!alive && takes)) {
+            const int got = wave_fetch_work(&counters[C_QA], !alive && takes, n, &exhausted);
             if (got >= 0) {
                 const int at = queue_index(a.q, got, n_front);
                 const float4 ro = a.q.o[at], rd = a.q.d[at], rw = a.q.w[at];
@@ -552,13 +562,14 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
+    const bool takes = (int)(threadIdx.x & 63) < lanes_in_use(n);
     bool alive = false, exhausted = false;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
     CameraPath P{};
     const int W = a.cam.w;
     while (true) {
-        if (!exhausted && !__all(alive)) {
-            const int got = wave_fetch_work(&counters[C_QA], !alive, n, &exhausted);
+        if (!exhausted && __any(!alive && takes)) {
+            const int got = wave_fetch_work(&counters[C_QA], !alive && takes, n, &exhausted);
             if (got >= 0) {
                 const int at = queue_index(a.q, got, n_front);
                 const float4 ro = a.q.o[at], rd = a.q.d[at], rw = a.q.w[at];
@@ -695,7 +706,9 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     // kernel that would find nothing to refill from are better left to it.
     int64_t want = divup(B, kPathBlock);
     if (ln.queued_last >= 0) want = std::max<int64_t>(divup(ln.queued_last * B / std::max<int64_t>(ln.batch_last, 1), 2 * kPathBlock), 256);
-    const int waves = (int)std::min<int64_t>(want, s->path_waves[KIND]);
+    // A rank of several traces a share of the paths and leaves much of its GPU idle: there the
+    // full grid, over which the kernel spreads the queue thinly, is the faster shape.
+    const int waves = s->world > 1 ? s->path_waves[KIND] : (int)std::min<int64_t>(want, s->path_waves[KIND]);
     k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
@@ -800,7 +813,7 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
     TK_HIP(hipMemsetAsync(&counters[C_QD], 0, 4, stream));
     k_camera_first<<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
-    const int waves = (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
+    const int waves = s->world > 1 ? s->path_waves[2] : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
     k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
