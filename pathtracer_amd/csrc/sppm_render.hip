@@ -159,10 +159,10 @@ TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
 // One bounce of a light path: closest hit, photon store at diffuse surfaces,
 // Russian roulette, BSDF sample (src/tracer/TkSppmTracer.cpp:124-156 for the
 // global map, :179-216 for the caustic map).  Returns true while the path lives.
-template <int KIND, class STACK>
-TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, bool* specular, STACK stk) {
+template <int KIND>
+TKD bool photon_on_hit(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, const Hit& h, bool* specular) {
     const DScene& sc = a.sc;
-    Hit h = trace_ray(sc, P.o, P.d, 1.7976931348623157e308, false, stk);
+    *specular = false;
     if (h.prim < 0) return false;
     SurfacePoint sp = surface_at(sc, h, P.o, P.d);
     F3 wo = neg3(P.d);
@@ -199,11 +199,21 @@ TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, b
     P.d = wi;
     return bounce + 1 < a.depth;
 }
+template <int KIND, class STACK>
+TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, bool* specular, STACK stk) {
+    const Hit h = trace_ray(a.sc, P.o, P.d, 1.7976931348623157e308, false, stk);
+    return photon_on_hit<KIND>(a, slot, bounce, P, h, specular);
+}
+
+constexpr int kPathBlock = 64;   // one wave per block: the kernels below use wave-wide votes as barriers
+// The path kernels go on (walk_rays returns) once all but 1/8 of the rays a
+// wave has in flight have finished: measured best among 1/2 .. 1/16; waiting
+// for every ray costs 3.5 %.
+constexpr int kWalkRestShift = 3;
 
 // Hands the idle lanes of a wave the next unstarted work items: returns this
 // lane's item or -1.  *exhausted turns true (for the whole wave) once the
 // cursor has passed n.  Every lane of the wave must call it.
-constexpr int kPathBlock = 64;   // one wave per block: the kernels below use wave-wide votes as barriers
 TKD int wave_fetch_work(int32_t* cursor, bool idle, int64_t n, bool* exhausted) {
     const unsigned long long m = __ballot(idle);
     const int want = __popcll(m);
@@ -272,9 +282,11 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     const bool takes = (int)(threadIdx.x & 63) < lanes_in_use(n);
-    bool alive = false, exhausted = false;
+    bool alive = false, exhausted = false, in_flight = false;
     int slot = 0, bounce = 0, traced = 0;
     PhotonPath P{};
+    RayWalk w;
+    w.cur = kWalkOver;
     while (true) {
         if (!exhausted && __any(!alive && takes)) {
             const int got = wave_fetch_work(&counters[C_QA], !alive && takes, n, &exhausted);
@@ -289,16 +301,23 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
                 P.flags = packed >> 24;
                 bounce = 1;
                 alive = true;
+                in_flight = false;
             }
         }
         if (!__any(alive)) {
             if (exhausted) break;
             continue;
         }
-        if (alive) {
+        if (alive && !in_flight) {
+            walk_begin(w, a.sc, P.d, 1.7976931348623157e308);
+            in_flight = true;
             ++traced;
+        }
+        walk_rays(a.sc, w, P.o, P.d, false, stk, __popcll(__ballot(alive)) >> kWalkRestShift);
+        if (alive && w.cur == kWalkOver) {   // this lane's ray has finished: the bounce, then its next ray
             bool specular;
-            alive = photon_step<KIND>(a, slot, bounce, P, &specular, stk);
+            alive = photon_on_hit<KIND>(a, slot, bounce, P, w.h, &specular);
+            in_flight = false;
             ++bounce;
             if (KIND == 0 && !alive) a.rec_count[slot] = P.flags;
         }
@@ -500,10 +519,8 @@ TKD void camera_emit_queries(const CameraArgs& a, int32_t* counters, const Camer
 // One turn of a camera path: traces the lane's ray (a path segment or the
 // pending shadow ray) and takes what follows from it.  Returns true while the
 // lane has another ray to trace.
-template <class STACK>
-TKD bool camera_turn(const CameraArgs& a, int x, int y, int pixel, int& bounce, CameraPath& P, CameraStepOut& so,
-                     STACK stk) {
-    const Hit h = trace_ray(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+TKD bool camera_after_ray(const CameraArgs& a, int x, int y, int pixel, int& bounce, CameraPath& P, CameraStepOut& so,
+                          const Hit& h) {
     if (P.shadow) {
         F3 Ld = P.ld_seen;
         if (h.prim < 0) Ld = add3(Ld, P.ld_light);
@@ -517,6 +534,12 @@ TKD bool camera_turn(const CameraArgs& a, int x, int y, int pixel, int& bounce, 
     const bool go_on = camera_on_hit(a, x, y, pixel, bounce, h, P, so);
     if (!P.shadow) ++bounce;
     return go_on;
+}
+template <class STACK>
+TKD bool camera_turn(const CameraArgs& a, int x, int y, int pixel, int& bounce, CameraPath& P, CameraStepOut& so,
+                     STACK stk) {
+    const Hit h = trace_ray(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+    return camera_after_ray(a, x, y, pixel, bounce, P, so, h);
 }
 
 // First stage of the camera pass: the camera ray of every pixel of this rank,
@@ -563,9 +586,11 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     const bool takes = (int)(threadIdx.x & 63) < lanes_in_use(n);
-    bool alive = false, exhausted = false;
+    bool alive = false, exhausted = false, in_flight = false;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
     CameraPath P{};
+    RayWalk w;
+    w.cur = kWalkOver;
     const int W = a.cam.w;
     while (true) {
         if (!exhausted && __any(!alive && takes)) {
@@ -580,17 +605,24 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
                 P.shadow = false;
                 y = pixel / W; x = pixel - y * W;
                 alive = true;
+                in_flight = false;
             }
         }
         if (!__any(alive)) {
             if (exhausted) break;
             continue;
         }
+        if (alive && !in_flight) {
+            walk_begin(w, a.sc, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308);
+            in_flight = true;
+            ++nrays;
+        }
+        walk_rays(a.sc, w, P.o, P.d, P.shadow, stk, __popcll(__ballot(alive)) >> kWalkRestShift);
         CameraStepOut so{};
         so.want_cq = so.want_gq = false;
-        if (alive) {
-            ++nrays;
-            alive = camera_turn(a, x, y, pixel, bounce, P, so, stk);
+        if (alive && w.cur == kWalkOver) {   // this lane's ray has finished: what follows from it, then its next ray
+            alive = camera_after_ray(a, x, y, pixel, bounce, P, so, w.h);
+            in_flight = false;
         }
         camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
     }

@@ -237,6 +237,63 @@ TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK
     return h;
 }
 
+// The same query as a walk that can be left and taken up again.  A wave that
+// traces one ray per lane with trace_ray runs as long as its slowest ray; the
+// kernels that walk whole paths call walk_rays instead, which returns once most
+// rays of the wave have finished: those lanes go on with their paths (and
+// start their next rays) while the slow rays simply continue in the next call.
+// The per-lane stack in LDS carries over between calls.
+constexpr int kWalkOver = 0x7fffffff;   // RayWalk::cur of a lane whose ray has finished (or that has none)
+struct RayWalk {
+    int cur;        // node to visit next, ~leaf to test next, or kWalkOver
+    int sp;
+    float tcull;
+    F3 dinv;
+    Hit h;
+};
+TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
+    w.h.prim = -1; w.h.t = tmax; w.h.u = 0; w.h.v = 0;
+    w.dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // see trace_ray
+    w.tcull = tmax >= 3.0e38 ? 3.4e38f : (float)tmax * 1.0000002f;
+    w.sp = 0;
+    w.cur = sc.n_nodes == 0 ? kWalkOver : 0;
+}
+// Advances the rays in flight (lanes with cur != kWalkOver; every lane of the
+// wave calls) until at most `rest` of them are unfinished.
+template <class STACK>
+TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest) {
+    while (true) {
+        while ((unsigned)w.cur < (unsigned)kWalkOver) {
+            const BvhNode nd = sc.nodes[w.cur];
+            float tl, tr;
+            const bool hl = box_hit(nd.lmin, nd.lmax, o, w.dinv, w.tcull, &tl);
+            const bool hr = box_hit(nd.rmin, nd.rmax, o, w.dinv, w.tcull, &tr);
+            if (hl && hr) {
+                const bool right_first = tr < tl;
+                st.push(w.sp, right_first ? nd.left : nd.right);
+                ++w.sp;
+                w.cur = right_first ? nd.right : nd.left;
+            } else if (hl) {
+                w.cur = nd.left;
+            } else if (hr) {
+                w.cur = nd.right;
+            } else if (w.sp > 0) {
+                --w.sp;
+                w.cur = st.pop(w.sp);
+            } else {
+                w.cur = kWalkOver;
+            }
+        }
+        if (w.cur != kWalkOver) {
+            leaf_test(sc, ~w.cur, o, d, &w.h);
+            w.tcull = w.h.t >= 3.0e38 ? 3.4e38f : (float)w.h.t * 1.0000002f;
+            if ((any_hit && w.h.prim >= 0) || w.sp == 0) w.cur = kWalkOver;
+            else { --w.sp; w.cur = st.pop(w.sp); }
+        }
+        if (__popcll(__ballot(w.cur != kWalkOver)) <= rest) break;
+    }
+}
+
 // Fills the surface record of a hit: Triangle::intersect :39-48 or
 // Sphere::intersect :39-53, and the object's material / light.
 TKD SurfacePoint surface_at(const DScene& sc, const Hit& h, F3 o, F3 d) {
