@@ -207,8 +207,7 @@ TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, b
 
 constexpr int kPathBlock = 64;   // one wave per block: the kernels below use wave-wide votes as barriers
 // The path kernels go on (walk_rays returns) once all but 1/8 of the rays a
-// wave has in flight have finished: measured best among 1/2 .. 1/16; waiting
-// for every ray costs 3.5 %.
+// wave has in flight have finished: measured best among 1/2 .. 1/32.
 constexpr int kWalkRestShift = 3;
 
 // Hands the idle lanes of a wave the next unstarted work items: returns this

@@ -186,64 +186,24 @@ TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h) {
 
 // Closest hit, or occlusion when any_hit is set (stops at the first hit below
 // tmax, enough for the boolean Scene::intersectP answers,
-// src/core/Scene.cpp:27-31).
+// src/core/Scene.cpp:27-31), as a walk that can be left and taken up again.
 //
-// Two nested loops: the inner one only walks inner nodes (two slab tests and a
-// push), and a lane leaves it when it holds a leaf; the primitive tests of the
-// leaf then run once the whole wave is out of the inner loop, with most lanes
-// taking part, instead of a few lanes at a time in the middle of the descent.
-// Stack entries are inner nodes (>= 0) or leaves (< 0, ~encoding).
-template <class STACK>
-TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK st) {
-    Hit h;
-    h.prim = -1; h.t = tmax; h.u = 0; h.v = 0;
-    if (sc.n_nodes == 0) return h;
-    // Ray ctor: direction_inv = float(1.0 / double(dir)) (src/Ray.hpp:21).  The correctly rounded
-    // fp32 quotient is the same number: 1/x for a 24-bit x never lies within a double's rounding
-    // error of a midpoint between two floats.
-    const F3 dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    constexpr int kDone = 0x7fffffff;
-    int sp = 0;
-    int cur = 0;
-    float tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
-    while (true) {
-        while ((unsigned)cur < (unsigned)kDone) {
-            const BvhNode nd = sc.nodes[cur];
-            float tl, tr;
-            const bool hl = box_hit(nd.lmin, nd.lmax, o, dinv, tcull, &tl);
-            const bool hr = box_hit(nd.rmin, nd.rmax, o, dinv, tcull, &tr);
-            if (hl && hr) {
-                const bool right_first = tr < tl;
-                st.push(sp, right_first ? nd.left : nd.right);
-                ++sp;
-                cur = right_first ? nd.right : nd.left;
-            } else if (hl) {
-                cur = nd.left;
-            } else if (hr) {
-                cur = nd.right;
-            } else if (sp > 0) {
-                --sp;
-                cur = st.pop(sp);
-            } else {
-                cur = kDone;
-            }
-        }
-        if (cur == kDone) break;
-        leaf_test(sc, ~cur, o, d, &h);
-        tcull = h.t >= 3.0e38 ? 3.4e38f : (float)h.t * 1.0000002f;
-        if ((any_hit && h.prim >= 0) || sp == 0) cur = kDone;
-        else { --sp; cur = st.pop(sp); }
-    }
-    return h;
-}
-
-// The same query as a walk that can be left and taken up again.  A wave that
-// traces one ray per lane with trace_ray runs as long as its slowest ray; the
-// kernels that walk whole paths call walk_rays instead, which returns once most
-// rays of the wave have finished: those lanes go on with their paths (and
-// start their next rays) while the slow rays simply continue in the next call.
-// The per-lane stack in LDS carries over between calls.
+// Two nested loops.  The inner one only walks inner nodes (two slab tests and
+// a push); a lane leaves it when it holds a leaf, and the loop ends as soon as
+// half of the wave's rays wait with a leaf (kLeafShare): waiting for every lane
+// would leave most of them idle behind the few with a long descent, and testing
+// each leaf at once would run the primitive tests with a few lanes at a time.
+// The lanes still descending sit out the leaf tests and carry on afterwards.
+// Stack entries are inner nodes (>= 0) or leaves (< 0, ~encoding); the per-lane
+// stack in LDS carries over between calls.
+//
+// A wave that traces one ray per lane to the end (trace_ray) runs as long as
+// its slowest ray.  The kernels that walk whole paths call walk_rays with
+// `rest` > 0 instead: it returns once all but `rest` rays of the wave have
+// finished, those lanes go on with their paths (and start their next rays),
+// and the slow rays simply continue in the next call.
 constexpr int kWalkOver = 0x7fffffff;   // RayWalk::cur of a lane whose ray has finished (or that has none)
+constexpr int kLeafShare = 8;           // sixteenths of the rays in flight that must hold a leaf before leaves are tested
 struct RayWalk {
     int cur;        // node to visit next, ~leaf to test next, or kWalkOver
     int sp;
@@ -253,17 +213,26 @@ struct RayWalk {
 };
 TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
     w.h.prim = -1; w.h.t = tmax; w.h.u = 0; w.h.v = 0;
-    w.dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // see trace_ray
+    // Ray ctor: direction_inv = float(1.0 / double(dir)) (src/Ray.hpp:21).  The correctly rounded
+    // fp32 quotient is the same number: 1/x for a 24-bit x never lies within a double's rounding
+    // error of a midpoint between two floats.
+    w.dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     w.tcull = tmax >= 3.0e38 ? 3.4e38f : (float)tmax * 1.0000002f;
     w.sp = 0;
     w.cur = sc.n_nodes == 0 ? kWalkOver : 0;
 }
-// Advances the rays in flight (lanes with cur != kWalkOver; every lane of the
-// wave calls) until at most `rest` of them are unfinished.
+// Advances the rays in flight (lanes with cur != kWalkOver) until at most
+// `rest` of them are unfinished.  Called by all the lanes that take part, in
+// step; the votes below count those lanes only.
 template <class STACK>
 TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest) {
     while (true) {
-        while ((unsigned)w.cur < (unsigned)kWalkOver) {
+        const int busy = __popcll(__ballot(w.cur != kWalkOver));
+        while (true) {
+            const bool inner = (unsigned)w.cur < (unsigned)kWalkOver;
+            const int n_inner = __popcll(__ballot(inner));
+            if (n_inner == 0 || (busy - n_inner) * 16 >= busy * kLeafShare) break;
+            if (!inner) continue;
             const BvhNode nd = sc.nodes[w.cur];
             float tl, tr;
             const bool hl = box_hit(nd.lmin, nd.lmax, o, w.dinv, w.tcull, &tl);
@@ -284,7 +253,7 @@ TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK
                 w.cur = kWalkOver;
             }
         }
-        if (w.cur != kWalkOver) {
+        if (w.cur < 0) {
             leaf_test(sc, ~w.cur, o, d, &w.h);
             w.tcull = w.h.t >= 3.0e38 ? 3.4e38f : (float)w.h.t * 1.0000002f;
             if ((any_hit && w.h.prim >= 0) || w.sp == 0) w.cur = kWalkOver;
@@ -292,6 +261,13 @@ TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK
         }
         if (__popcll(__ballot(w.cur != kWalkOver)) <= rest) break;
     }
+}
+template <class STACK>
+TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK st) {
+    RayWalk w;
+    walk_begin(w, sc, d, tmax);
+    walk_rays(sc, w, o, d, any_hit, st, 0);
+    return w.h;
 }
 
 // Fills the surface record of a hit: Triangle::intersect :39-48 or
