@@ -32,9 +32,15 @@
 
 namespace tkd {
 
-constexpr int kCounterBytes = 64;
-
-enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 1, C_NGQ = 2, C_NCQ = 3, C_TOTAL = 4, C_USED = 5, C_RAYS = 6 /* u64 */, C_PHOT = 8 /* u64 */, C_CAND = 10 /* u64 */, C_QD = 12 };
+// Counters of a pass.  Those that many waves hit with atomics at the same time
+// (the work cursor of the path kernels, the two query appends, the two ends of
+// the path queue) sit in 128-byte lines of their own: sharing one line cost
+// 4 % of the iteration.  Everything before kCounterBatchInts is cleared for
+// every batch of a pass; the 64-bit totals behind it run over the whole pass.
+enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 32, C_QD = 64, C_NGQ = 96, C_NCQ = 128, C_TOTAL = 160, C_USED = 161,
+       C_RAYS = 192 /* u64 */, C_PHOT = 194 /* u64 */, C_CAND = 196 /* u64 */ };
+constexpr int kCounterBatchInts = 192;
+constexpr int kCounterBytes = 256 * 4;
 
 // Everything one concurrently running pass needs: its stream, path state,
 // queues, counters and scratch.  Lane 0 traces the global photons and builds
@@ -580,11 +586,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int6
 // Second stage: the queued paths from their second segment on, organised like
 // k_photon_paths; every turn of the loop traces one ray per lane, path
 // segments and shadow rays side by side.
-__global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int32_t* counters) {
+__global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int spread, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
-    const bool takes = (int)(threadIdx.x & 63) < lanes_in_use(n);
+    if (!spread && (int64_t)blockIdx.x * 64 >= n) return;   // the waves before this one take the whole queue
+    const bool takes = !spread || (int)(threadIdx.x & 63) < lanes_in_use(n);
     bool alive = false, exhausted = false, in_flight = false;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
     CameraPath P{};
@@ -728,8 +735,7 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     // start of the iteration so that the two passes do not depend on each other
     a.hoff = KIND == 0 ? 0 : s->caustic_hoff;
     a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
-    TK_HIP(hipMemsetAsync(counters, 0, 6 * 4, stream));
-    TK_HIP(hipMemsetAsync(&counters[C_QD], 0, 4, stream));
+    TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
     k_photon_first<KIND><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
     // Second-stage grid: enough waves for two path loads each of what the queue held last time (the
     // long paths need the refill to keep their waves full), at most what fits the GPU.  The photon
@@ -840,14 +846,13 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.cq = s->qbuf[1].as<float4>();
     a.qcap = s->n_slots;
     a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)s->n_slots};
-    TK_HIP(hipMemsetAsync(counters, 0, 4 * 4, stream));
+    TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
     TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
-    TK_HIP(hipMemsetAsync(&counters[C_QD], 0, 4, stream));
     k_camera_first<<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
     const int waves = s->world > 1 ? s->path_waves[2] : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
-    k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, counters);
+    k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
     TK_LAUNCH_CHECK();
-    TK_HIP(hipMemcpyAsync(ln.h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
+    TK_HIP(hipMemcpyAsync(ln.h_counters, counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
     return TKHIP_OK;
 }
 // Waits for the camera paths launched last and takes their query counts.
@@ -1021,11 +1026,11 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     int lane_no = 0;
     for (Lane& l : s->lane) {
         if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio[lane_no++]) != hipSuccess) { set_error("tkhip_sppm_begin: hipStreamCreate failed"); rc = TKHIP_E_HIP; break; }
-        rc = l.counters.ensure(64);
+        rc = l.counters.ensure(kCounterBytes);
         if (rc) break;
-        if (hipHostMalloc(reinterpret_cast<void**>(&l.h_counters), 64, hipHostMallocDefault) != hipSuccess) { set_error("tkhip_sppm_begin: pinned allocation failed"); rc = TKHIP_E_NOMEM; break; }
-        std::memset(l.h_counters, 0, 64);
-        if (hipMemsetAsync(l.counters.p, 0, 64, l.stream) != hipSuccess) { set_error("tkhip_sppm_begin: memset failed"); rc = TKHIP_E_HIP; break; }
+        if (hipHostMalloc(reinterpret_cast<void**>(&l.h_counters), kCounterBytes, hipHostMallocDefault) != hipSuccess) { set_error("tkhip_sppm_begin: pinned allocation failed"); rc = TKHIP_E_NOMEM; break; }
+        std::memset(l.h_counters, 0, kCounterBytes);
+        if (hipMemsetAsync(l.counters.p, 0, kCounterBytes, l.stream) != hipSuccess) { set_error("tkhip_sppm_begin: memset failed"); rc = TKHIP_E_HIP; break; }
     }
     if (!rc) {
         hipDeviceProp_t prop{};
