@@ -241,6 +241,15 @@ typedef struct TkGatherTotals {
 } TkGatherTotals;
 int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset);
 
+/* Starts the photon passes of iteration `iter` (the first batch of light paths
+ * of both maps) and returns at once; tkhip_sppm_photon_pass(iter) then picks
+ * them up.  Optional, like tkhip_sppm_camera_begin below: a multi-GPU driver
+ * calls this first, then tkhip_sppm_camera_begin, so that the light paths (which
+ * the exchange waits for) are ahead of the camera paths in the GPU's queues.
+ * No counterpart in the reference, whose photon pass and camera pass follow
+ * each other (src/tracer/TkSppmTracer.cpp:411-421, :480-496). */
+int tkhip_sppm_photon_begin(tkhip_ctx* ctx, int iter);
+
 /* Starts the camera paths of iteration `iter` (the part of traceTile that does
  * not read the photon maps, src/tracer/TkSppmTracer.cpp:296-321, :341-371) and
  * returns at once; tkhip_sppm_camera_pass(iter) then picks them up.  Optional:

@@ -103,6 +103,7 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_build_maps": (C.c_int, [C.c_void_p, C.POINTER(TkIterStats)]),
     "tkhip_sppm_set_tree": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_camera_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "tkhip_sppm_photon_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_gather_totals": (C.c_int, [C.c_void_p, C.POINTER(TkGatherTotals), C.c_int]),
     "tkhip_sppm_camera_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),

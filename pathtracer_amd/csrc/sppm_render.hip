@@ -76,6 +76,8 @@ struct SppmState {
     int64_t n_loc[2] = {0, 0}, last_shot[2] = {0, 0}, local_shot[2] = {0, 0}, shoot[2] = {0, 0};
     int64_t stored_c = 0;
     int64_t last_gather_photons[2] = {0, 0}, last_gather_staged[2] = {0, 0};   // of the last timed gather
+    bool photon_begun = false;       // tkhip_sppm_photon_begin has enqueued the first batches
+    int64_t begun_batch[2] = {0, 0};
     int camera_in_flight = -1;       // iteration whose camera paths have been launched and not yet waited for
     int64_t caustic_hoff = 0;        // global paths shot before the current iteration
     double yield[2] = {2.0, 0.05};
@@ -1086,15 +1088,25 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     return TKHIP_OK;
 }
 
-int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
-    TK_CTX_SPPM(ctx, "tkhip_sppm_photon_pass");
+int tkhip_sppm_photon_begin(tkhip_ctx* ctx, int iter) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_photon_begin");
     (void)iter;
     SppmState* s = ctx->sppm;
-    double t0 = now_ms();
+    TK_REQUIRE(!s->photon_begun, TKHIP_E_STATE, "tkhip_sppm_photon_begin: a photon pass is already in flight");
     s->caustic_hoff = s->local_shot[0];
-    int64_t Bg = 0, Bc = 0;
-    TK_TRY(photon_pass_begin<0>(ctx, &Bg));      // both passes are in flight together
-    TK_TRY(photon_pass_begin<1>(ctx, &Bc));
+    TK_TRY(photon_pass_begin<0>(ctx, &s->begun_batch[0]));      // both passes are in flight together
+    TK_TRY(photon_pass_begin<1>(ctx, &s->begun_batch[1]));
+    s->photon_begun = true;
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_photon_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_photon_pass");
+    SppmState* s = ctx->sppm;
+    double t0 = now_ms();
+    if (!s->photon_begun) TK_TRY(tkhip_sppm_photon_begin(ctx, iter));
+    s->photon_begun = false;
+    const int64_t Bg = s->begun_batch[0], Bc = s->begun_batch[1];
     TK_TRY(photon_pass_finish<0>(ctx, Bg));
     TK_TRY(photon_pass_finish<1>(ctx, Bc));
     if (s->world == 1) {
@@ -1190,6 +1202,7 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     SppmState* s = ctx->sppm;
     TK_REQUIRE(s->world == 1, TKHIP_E_STATE,
                "tkhip_sppm_iteration: with world > 1 drive the passes and the photon exchange separately");
+    TK_REQUIRE(!s->photon_begun, TKHIP_E_STATE, "tkhip_sppm_iteration: finish the photon pass begun with tkhip_sppm_photon_begin first");
     const double t0 = now_ms();
     double t_photon_end[2] = {t0, t0}, build_ms[2] = {0, 0};
     // Enqueue in the order of the critical path: the global pass (the longest chain: pass, then

@@ -69,20 +69,23 @@ class HipBackend:
         power = torch.zeros((cap, 3), dtype=torch.float32, device=self.dev)
         direction = torch.zeros((cap,), dtype=torch.int16, device=self.dev)
         n, shot = C.c_int64(), C.c_int64()
-        torch.cuda.synchronize(self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()   # torch's work on these buffers, not the lanes of the library
         check(self.lib, self.lib.tkhip_sppm_export_local_photons(self.h, which, pos.data_ptr(), power.data_ptr(),
                                                                  direction.data_ptr(), cap, C.byref(n), C.byref(shot)),
               "tkhip_sppm_export_local_photons")
         return pos, power, direction, n.value, shot.value
 
     def set_map(self, which, pos, power, direction, n, shot_total):
-        torch.cuda.synchronize(self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()   # torch's work on these buffers, not the lanes of the library
         check(self.lib, self.lib.tkhip_sppm_set_map_photons(self.h, which, pos.data_ptr(), power.data_ptr(),
                                                             direction.data_ptr(), n, shot_total),
               "tkhip_sppm_set_map_photons")
 
     def build_maps(self, stats=None):
         self.tracer.build_maps(stats)
+
+    def photon_begin(self, it):
+        check(self.lib, self.lib.tkhip_sppm_photon_begin(self.h, it), "tkhip_sppm_photon_begin")
 
     def camera_begin(self, it):
         check(self.lib, self.lib.tkhip_sppm_camera_begin(self.h, it), "tkhip_sppm_camera_begin")
@@ -97,7 +100,7 @@ class HipBackend:
 
     def import_planes(self, planes):
         planes = planes.contiguous()
-        torch.cuda.synchronize(self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()   # torch's work on these buffers, not the lanes of the library
         check(self.lib, self.lib.tkhip_sppm_import_planes(self.h, planes.data_ptr()), "tkhip_sppm_import_planes")
 
     def resolve(self):
@@ -166,7 +169,10 @@ def iteration(backend, it, world, stats=None):
         backend.iteration_single(it, stats)
         return [None, None]
     if hasattr(backend, "camera_begin"):
-        backend.camera_begin(it)   # camera paths do not read the maps: trace them beside the photon phase
+        # camera paths do not read the maps: trace them beside the photon phase, behind the light paths
+        # in the GPU's queues (the exchange waits for those)
+        backend.photon_begin(it)
+        backend.camera_begin(it)
     backend.photon_pass(it, stats)
     totals = exchange_photons(backend, world)
     backend.build_maps(stats)

@@ -1,40 +1,40 @@
-"""Times an iteration driven phase by phase (the multi-rank code path) on one rank (profiling helper, not a test)."""
+"""Times one rank of a multi-rank render on one GPU (profiling helper, not a test): the rank runs
+distributed.iteration() as rank 0 of `world`, with the all-gather replaced by `world` copies of its own table, so
+that it traces its share of the paths and builds and gathers maps of the full size."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pathtracer_amd import distributed as D
 from pathtracer_amd.scene import Scene, asset_scene
 
+D._all_gather = lambda t, world: [t] * world
 scene = Scene.load(asset_scene("cornell_dragon.scene"))
 param = scene.sppm_param()
-for world in (1, 2, 8):
+for world in (1, 2, 4, 8):
     be = D.HipBackend(scene, param, 20, 0.8, 0x5EED, 1024, 1024, 0, world, 0)
-    def step(it):
-        be.camera_begin(it)
-        be.photon_pass(it)
-        if world > 1:   # this rank's share only: install it as if it were the whole map
-            for which in (0, 1):
-                pos, power, d, n, shot = be.export_local(which)
-                be.set_map(which, pos, power, d, n, shot)
-        be.build_maps()
-        be.camera_pass(it)
+    if world == 1:
+        be_step = lambda it: be.iteration_single(it)
+    else:
+        be_step = lambda it: D.iteration(be, it, world)
     for it in range(5):
-        step(it)
+        be_step(it)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(5, 25):
-        step(it)
+        be_step(it)
     torch.cuda.synchronize()
-    # one more iteration, phase by phase with a synchronisation after each
+    ms = (time.perf_counter() - t0) / 20 * 1e3
     ph = {}
     def timed(name, fn):
-        torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
+        torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
         ph[name] = ph.get(name, 0.0) + (time.perf_counter() - t) * 1e3
-    for it in range(25, 28):
-        timed("photon_pass", lambda: be.photon_pass(it))
-        timed("build", lambda: be.build_maps())
-        timed("camera_begin+wait", lambda: (be.camera_begin(it), torch.cuda.synchronize()))
-        timed("camera_pass(gathers)", lambda: be.camera_pass(it))
-    print("   phases alone, ms:", {k: round(v / 3, 2) for k, v in ph.items()})
-    print("rank 0 of", world, ":", (time.perf_counter() - t0) / 20 * 1e3, "ms per iteration, phase by phase (no collective)")
+        return r
+    if world > 1:
+        for it in range(25, 28):
+            timed("photon pass", lambda: be.photon_pass(it))
+            timed("exchange", lambda: D.exchange_photons(be, world))
+            timed("builds", lambda: be.build_maps())
+            timed("camera paths", lambda: (be.camera_begin(it), torch.cuda.synchronize()))
+            timed("gathers", lambda: be.camera_pass(it))
+    print("rank 0 of %d: %.2f ms per iteration; phases alone, ms: %s" % (world, ms, {k: round(v / 3, 2) for k, v in ph.items()}), flush=True)
     be.close()
