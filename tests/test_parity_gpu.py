@@ -423,7 +423,8 @@ def test_two_rank_sharding_on_one_gpu():
     ors = [O.OracleSppm(osc, prm, 20, 0.8, 0x5EED, rank=r, world=2, threads=4) for r in range(2)]
     for it in range(2):
         for be, orc in zip(bes, ors):
-            be.camera_begin(it)        # camera paths traced beside the photon phase, as the multi-rank driver does
+            be.photon_begin(it)        # light paths enqueued first, camera paths traced beside them,
+            be.camera_begin(it)        # as the multi-rank driver does
             be.photon_pass(it)
             orc.photon_pass(it)
         for which, size in ((0, GS), (1, CS)):
