@@ -77,6 +77,8 @@ int map_build(tkhip_map* m);
 // grouped kernel's duration with events (synchronises).
 // Sizes the scratch of gathers of up to nq queries (so that later gathers do not reallocate).
 int map_reserve_queries(tkhip_map* m, int64_t nq);
+// Sizes what map_build needs for a full map.
+int map_reserve_build(tkhip_map* m);
 // Adds the pending event pair to the running totals (waits for the launch it brackets).
 int map_flush_timing(tkhip_map* m);
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed);

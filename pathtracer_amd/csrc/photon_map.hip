@@ -826,6 +826,22 @@ int map_set_photons_device(tkhip_map* m, const float* pos, const float* power, c
     return TKHIP_OK;
 }
 
+int map_reserve_build(tkhip_map* m) {
+    const int64_t n = std::max<int64_t>(m->cap, 1);
+    int64_t want = (n + kLeafCap - 1) / kLeafCap;
+    int nl = 1;
+    while (nl < want) nl <<= 1;
+    TK_TRY(m->pos4.ensure((size_t)n * 16));
+    TK_TRY(m->pow4.ensure((size_t)n * 16));
+    TK_TRY(m->node_box.ensure((size_t)nl * 2 * 32));
+    TK_TRY(m->idx_a.ensure((size_t)n * 4));
+    TK_TRY(m->idx_b.ensure((size_t)n * 4));
+    TK_TRY(m->key_a.ensure((size_t)n * 4));
+    TK_TRY(m->key_b.ensure((size_t)n * 4));
+    TK_TRY(m->root_box.ensure(64));
+    return sort_pairs_u32_reserve(m->prim_temp, (size_t)n, 30);
+}
+
 int map_build(tkhip_map* m) {
     hipStream_t s = m->stream;
     const int64_t n = m->n;

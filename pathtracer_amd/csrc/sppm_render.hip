@@ -1079,10 +1079,52 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
     for (DevBuf* b : {&s->lane[2].q_o, &s->lane[2].q_d, &s->lane[2].q_w})
         if (!rc) rc = b->ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 16);
+    // Everything an iteration would otherwise allocate on first use: the tree and gather scratch of
+    // both maps, and the staging of a first batch of light paths (sized as photon_launch_batch does).
+    for (int w = 0; w < 2 && !rc; ++w) {
+        rc = map_reserve_build(s->map[w]);
+        if (!rc) rc = map_reserve_queries(s->map[w], std::max<int64_t>(s->n_slots, 1));
+        if (s->quota[w] <= 0) continue;
+        Lane& ln = s->lane[w];
+        const size_t B = (size_t)std::min<int64_t>((int64_t)((double)s->quota[w] / s->yield[w] * 1.02) + 256, (int64_t)1 << 24);
+        const size_t slots = w == 0 ? (size_t)max_depth : 1;
+        for (DevBuf* b : {&ln.stage_pos, &ln.stage_pow})
+            if (!rc) rc = b->ensure(B * slots * 16);
+        for (DevBuf* b : {&ln.rec_count, &ln.rec_offset})
+            if (!rc) rc = b->ensure(B * 4);
+        for (DevBuf* b : {&ln.q_o, &ln.q_d, &ln.q_w})
+            if (!rc) rc = b->ensure(B * 16);
+    }
     if (rc) { destroy_sppm(ctx); return rc; }
     if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     k_init_planes<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, param->radius2);
     TK_LAUNCH_CHECK();
+    // One launch of each path kernel on an empty queue (the counters are zero): the first launch of a
+    // kernel loads its code and sets up the scratch memory its register spills need, milliseconds
+    // that would otherwise fall into the first iteration.
+    {
+        PhotonArgs pa{};
+        pa.sc = ctx->scene;
+        CameraArgs ca{};
+        ca.sc = ctx->scene; ca.cam = ctx->cam;
+        k_photon_paths<0><<<s->path_waves[0], kPathBlock, 0, s->lane[0].stream>>>(pa, s->lane[0].counters.as<int32_t>());
+        k_photon_paths<1><<<s->path_waves[1], kPathBlock, 0, s->lane[1].stream>>>(pa, s->lane[1].counters.as<int32_t>());
+        k_camera_paths<<<s->path_waves[2], kPathBlock, 0, s->lane[2].stream>>>(ca, 1, s->lane[2].counters.as<int32_t>());
+        TK_LAUNCH_CHECK();
+        // likewise the scan and the sort of the library the passes use (their first call is slow)
+        for (int w = 0; w < 2; ++w) {
+            Lane& ln = s->lane[w];
+            if (s->quota[w] <= 0) continue;
+            TK_HIP(hipMemsetAsync(ln.rec_count.p, 0, 1024 * 4, ln.stream));
+            TK_TRY(exclusive_scan_i32(ln.stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), 1024));
+            tkhip_map* m = s->map[w];
+            if (m->cap >= 2048) {
+                TK_HIP(hipMemsetAsync(m->key_a.p, 0, 2048 * 4, m->stream));
+                TK_TRY(sort_pairs_u32(m->stream, m->prim_temp, m->key_a.as<uint32_t>(), m->key_b.as<uint32_t>(), m->idx_a.as<uint32_t>(),
+                                      m->idx_b.as<uint32_t>(), 2048, 30));
+            }
+        }
+    }
     TK_HIP(hipStreamSynchronize(ctx->stream));
     for (Lane& l : s->lane) TK_HIP(hipStreamSynchronize(l.stream));
     return TKHIP_OK;
