@@ -4,9 +4,11 @@
 // Shape of the work: a pass has two stages.  The first traces the first
 // segment of every path, one path per lane in plain full waves (these rays are
 // alike and cheap); paths that go on are queued.  The second is one launch
-// whose grid fills the GPU once: each lane walks a queued path to its end,
-// bounce by bounce, and takes the next queued path when its own ends (the
-// LDS-stack traversal of tk_bvh_device.h traces the rays):
+// whose grid fills the GPU once: each lane walks a queued path to its end and
+// takes the next queued path when its own ends.  Its rays are the resumable
+// walks of tk_bvh_device.h: a wave does not wait for its slowest ray before it
+// goes on, the lanes whose rays have finished shade and start their next rays
+// while the slow rays continue:
 //   photon pass : k_photon_first<KIND> -> k_photon_paths<KIND> -> scan -> k_photon_scatter
 //                 (tracePhoton / traceCausticPhoton, src/tracer/TkSppmTracer.cpp:104-217)
 //   camera pass : k_camera_first -> k_camera_paths -> gathers
@@ -280,9 +282,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
 }
 
 // Second stage: the queued paths from their second segment on.  The grid is
-// sized to fill the GPU once; every lane walks one path at a time, bounce by
-// bounce in step with its wave, and a lane whose path has ended takes the next
-// queued path, so that waves stay full until the queue runs out.
+// sized to fill the GPU once; every lane walks one path at a time, and a lane
+// whose path has ended takes the next queued path, so that waves stay full
+// until the queue runs out.  A turn of the loop advances the rays in flight
+// (walk_rays) until all but an eighth of them have finished; the lanes whose
+// ray is over take the bounce and start their next ray, the others keep
+// walking theirs in the next turn.
 template <int KIND>
 __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
@@ -586,8 +591,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int6
 }
 
 // Second stage: the queued paths from their second segment on, organised like
-// k_photon_paths; every turn of the loop traces one ray per lane, path
-// segments and shadow rays side by side.
+// k_photon_paths; path segments and shadow rays are in flight side by side.
+// spread: see lanes_in_use; otherwise the queue fills whole waves.
 __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int spread, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
