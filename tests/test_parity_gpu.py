@@ -175,6 +175,64 @@ def test_knn_matches_oracle_random(gpu_ctx, n, k, nq):
     om.close()
 
 
+def test_knn_many_photons_at_one_distance(gpu_ctx):
+    """Hundreds of photons at the same spot: the k-th nearest falls among keys that differ in the photon index only
+    (more of them than the binned selection ranks at once).  Expected sets by the index rule (brute force): the CPU
+    code keeps whichever of the tied photons its traversal meets first."""
+    rng = np.random.default_rng(77)
+    pos, power, th, ph = make_photons(rng, 3000)
+    spots = pos[:3].copy()
+    pos[100:500] = spots[0]
+    pos[900:1100] = spots[1]
+    pos[2000:2090] = spots[2]
+    qp, qn, qwo, qR, r2 = make_queries(rng, 600, radius2=(0.08, 0.5, 30.0))
+    qp[:300] = spots[rng.integers(0, 3, 300)] + rng.normal(scale=1e-3, size=(300, 3)).astype(np.float32)
+    d = pos[None, :, :] - qp[:, None, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]          # the fp32 expression of the kernels
+    for k in (50, 100, 448):
+        want_idx = np.full((len(qp), k), 1 << 30, np.int64)
+        want_found = np.zeros(len(qp), np.int32)
+        want_r2 = r2.copy()
+        for i in range(len(qp)):
+            cand = np.nonzero(d2[i] < r2[i])[0]
+            keep = cand[np.lexsort((cand, d2[i][cand]))[:k]]
+            want_idx[i, :len(keep)] = np.sort(keep)
+            want_found[i] = len(keep)
+            if len(keep) == k:
+                want_r2[i] = d2[i][keep].max()
+        flux_ref = None
+        for tree in (0, 1):
+            gm = _gpu_map(gpu_ctx, (pos, power, th, ph), k, tree)
+            for mode in (0, 1):
+                gf, gfound, gr2, gidx = gm.gather(qp, qn, qwo, qR, r2, mode=mode)
+                got = np.sort(np.where(gidx < 0, 1 << 30, gidx).astype(np.int64), axis=1)
+                assert (gfound == want_found).all() and (got == want_idx).all() and (gr2 == want_r2).all()
+                if flux_ref is None:
+                    flux_ref = gf
+                _flux_close(gf, flux_ref)      # same photons kept: the four ways of getting there agree
+            gm.close()
+
+
+def test_photon_begin_state_checks():
+    """tkhip_sppm_photon_begin: a second call, or a whole iteration, while a pass is in flight is refused; the pass
+    it starts is the one tkhip_sppm_photon_pass finishes."""
+    from pathtracer_amd import distributed as D
+    scene = Scene.load(asset_scene("cornell_box.scene"))
+    prm = scene.sppm_param(globalSize=4000, causticSize=0, numRecurse=4)
+    be = D.HipBackend(scene, prm, 20, 0.8, 0x5EED, 32, 32, 0, 1, 0)
+    be.photon_begin(0)
+    with pytest.raises(_abi.TkError):
+        be.photon_begin(0)
+    with pytest.raises(_abi.TkError):
+        be.iteration_single(0)
+    st = _abi.TkIterStats()
+    be.photon_pass(0, st)
+    assert st.global_stored == 4000 and st.global_paths > 0
+    be.build_maps(); be.camera_pass(0)
+    be.iteration_single(1)
+    be.close()
+
+
 def test_knn_edge_cases(gpu_ctx):
     rng = np.random.default_rng(8)
     qp, qn, qwo, qR, r2 = make_queries(rng, 130)
