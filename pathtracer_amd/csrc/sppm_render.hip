@@ -89,6 +89,7 @@ struct SppmState {
     int n_rows = 0;
     int64_t n_slots = 0;
     Lane lane[3];
+    int photon_loads = 3;            // see photon_launch_batch
     int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
     DevBuf qbuf[2];
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
@@ -744,12 +745,14 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
     k_photon_first<KIND><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
-    // Second-stage grid: enough waves for two path loads each of what the queue held last time (the
-    // long paths need the refill to keep their waves full), at most what fits the GPU.  The photon
-    // passes share the GPU with the camera pass, whose queue is the longest: waves of a light-path
-    // kernel that would find nothing to refill from are better left to it.
+    // Second-stage grid: enough waves for `photon_loads` path loads each of what the queue held last
+    // time (the long paths need the refill to keep their waves full), at most what fits the GPU.  The
+    // photon passes share the GPU with the camera pass: every wave slot a light-path kernel does not
+    // hold goes to the camera paths.  tkhip_sppm_iteration steers photon_loads so that the photon chains
+    // (pass, then tree build) end shortly before the camera paths do: with the dragon it settles at 5-6
+    // (197 -> 208 iterations/s against a fixed 2; at 7 the caustic pass would be the longest chain).
     int64_t want = divup(B, kPathBlock);
-    if (ln.queued_last >= 0) want = std::max<int64_t>(divup(ln.queued_last * B / std::max<int64_t>(ln.batch_last, 1), 2 * kPathBlock), 256);
+    if (ln.queued_last >= 0) want = std::max<int64_t>(divup(ln.queued_last * B / std::max<int64_t>(ln.batch_last, 1), s->photon_loads * kPathBlock), 256);
     // A rank of several traces a share of the paths and leaves much of its GPU idle: there the
     // full grid, over which the kernel spreads the queue thinly, is the faster shape.
     const int waves = s->world > 1 ? s->path_waves[KIND] : (int)std::min<int64_t>(want, s->path_waves[KIND]);
@@ -1286,6 +1289,16 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     const double t_cam = now_ms();
     int rc_g = wg.join();
     int rc_c = wc.join();
+    {
+        // the maps are ready at photon_done, the gather queries at camera_done: the later of the two
+        // sets the iteration, and wave slots move from the one to the other through photon_loads
+        const double photon_done = std::max(t_photon_end[0] + build_ms[0], t_photon_end[1] + build_ms[1]) - t0;
+        const double camera_done = t_cam - t0;
+        if (photon_done > 1.05 * camera_done) s->photon_loads = std::max(1, s->photon_loads - 1);
+        else if (photon_done < 0.95 * camera_done) s->photon_loads = std::min(8, s->photon_loads + 1);
+        static const bool verbose = getenv("TKHIP_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "tkhip: iteration %d: maps ready %.2f ms, queries ready %.2f ms -> photon_loads %d\n", iter, photon_done, camera_done, s->photon_loads);
+    }
     if (rc_g != TKHIP_OK) return rc_g;
     if (rc_c != TKHIP_OK) return rc_c;
     if (rc_cam != TKHIP_OK) return rc_cam;
