@@ -52,6 +52,7 @@ struct tkhip_map {
     int tree_mode = 0;              // 0: one sort along a Hilbert curve; 1: median splits, one sort per level
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
+    tkd::DevBuf overflow_group, group_leaves, group_leaf_count;   // what the grouped kernel hands on with a query
     float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)
     int64_t last_overflow = 0;   // queries the last timed gather handed to the per-query kernel
     // Every grouped-kernel launch is bracketed by this pair of events on the map's stream (recording

@@ -453,9 +453,18 @@ TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay
 static_assert(64 % kLeafCap == 0, "a step of a gather kernel serves 64 / kLeafCap leaves, one photon per lane");
 constexpr int kLeavesPerStep = 64 / kLeafCap;
 
+// What the grouped kernel hands to the per-query kernel with a query: the group it was in, and per
+// group the leaves under the union of its search boxes (at most kMaxGroupLeaves <= 64).
+constexpr int kMaxGroupLeaves = 24 * kLeavesPerStep;
+struct GroupLeaves {
+    int32_t* query_group;   // per entry of the hand-over list: group, or -1 (search from the root)
+    int32_t* leaves;        // kMaxGroupLeaves node numbers per group
+    int32_t* count;
+};
+
 template <int EPL>
 __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, const int32_t* list,
-                                                     const int32_t* list_count, int64_t nq, GatherOut out) {
+                                                     const int32_t* list_count, int64_t nq, GatherOut out, GroupLeaves gl) {
     constexpr int CAP = 64 * EPL;
     constexpr int FCAP = 128 * kLeavesPerStep;   // frontier entries of the level-by-level descent
     __shared__ unsigned long long s_keys[4][CAP];
@@ -526,14 +535,25 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
             const int l0 = mv.depth < 6 ? mv.depth : 6;
             const int n0 = 1 << l0;
             bool fits = true;
-            for (int base = 0; base < n0; base += 64) {
+            // A query handed on by the grouped kernel comes with the leaves under its group's search
+            // boxes: those within its own reach are the leaves the descent below would end with.
+            const int gid = (list && gl.query_group) ? gl.query_group[w] : -1;
+            if (gid >= 0) {
+                const int have = gl.count[gid];
+                const int node = lane < have ? gl.leaves[(int64_t)gid * kMaxGroupLeaves + lane] : 0;
+                const bool keep = lane < have && box_dist2(mv, node, Q.p) < bound_d2;
+                const unsigned long long m = __ballot(keep);
+                if (keep) front[cur][__popcll(m & lt_mask)] = node;
+                fcount = __popcll(m);
+            }
+            for (int base = 0; base < n0 && gid < 0; base += 64) {
                 const int node = n0 + base + lane;
                 const bool keep = base + lane < n0 && box_dist2(mv, node, Q.p) < bound_d2;
                 unsigned long long m = __ballot(keep);
                 if (keep) front[cur][fcount + __popcll(m & lt_mask)] = node;
                 fcount += __popcll(m);
             }
-            for (int level = l0; level < mv.depth && fits; ++level) {
+            for (int level = l0; level < mv.depth && fits && gid < 0; ++level) {
                 int ncount = 0;
                 for (int e0 = 0; e0 < 2 * fcount; e0 += 64) {
                     const int e = e0 + lane;
@@ -626,11 +646,11 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
 // A query that meets fewer than k photons inside its radius is finished here
 // (no selection is needed: found < k keeps them all and leaves the radius
 // unchanged); the rest go to the per-query kernel.
-constexpr int kMaxGroupLeaves = 24 * kLeavesPerStep;
 
 template <bool WANT_IDX>
 __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, const uint32_t* order, int64_t nq,
-                                                      GatherOut out, int32_t* overflow, int32_t* overflow_count) {
+                                                      GatherOut out, int32_t* overflow, int32_t* overflow_count,
+                                                      GroupLeaves gl) {
     constexpr int FCAP = 64 * kLeavesPerStep;
     __shared__ float s_tab[1024];
     __shared__ float4 s_pos[4][64];   // x, y, z, original index
@@ -666,6 +686,7 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         const int n_live = __popcll(__ballot(Q.r2 > 0.f));
         bool spread = n_live > 0 && (hix - lox) * (hiy - loy) * (hiz - loz) * (float)n_live > 64.f * own_sum;
         int cnt = 0;
+        int cur = 0, fcount = 0;
         float sx = 0, sy = 0, sz = 0;
         auto overlaps = [&](int node) {
             const float4 b0 = mv.node_box[2 * (int64_t)node], b1 = mv.node_box[2 * (int64_t)node + 1];
@@ -673,7 +694,6 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         };
         if (mv.n > 0 && lox <= hix && !spread) {
             // 1. leaves under the union box, level by level
-            int cur = 0, fcount = 0;
             const int l0 = mv.depth < 6 ? mv.depth : 6;
             const int n0 = 1 << l0;
             {
@@ -750,6 +770,13 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         if (valid && !over) finish_query(out, q, Q, cnt, Q.r2 > 0.f ? Q.r2 : qv.q0[q].w, mk3(sx, sy, sz));
         int dst = wave_append(overflow_count, over);
         if (over) overflow[dst] = (int32_t)q;
+        // the per-query kernel starts from this group's leaves instead of the root
+        const bool with_leaves = !spread && mv.n > 0 && lox <= hix;
+        if (over) gl.query_group[dst] = with_leaves ? (int32_t)g : -1;
+        if (with_leaves && __any(over)) {
+            if (lane < fcount) gl.leaves[g * kMaxGroupLeaves + lane] = front[cur][lane];
+            if (lane == 0) gl.count[g] = fcount;
+        }
         float fs = wave_sum(valid && !over ? (float)cnt : 0.f);
         found_sum += (unsigned long long)fs;
     }
@@ -804,7 +831,8 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
 void map_destroy(tkhip_map* m) {
     if (!m) return;
     DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->node_axis, &m->clip_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
-                      &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters, &m->prim_temp};
+                      &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->overflow, &m->counters, &m->prim_temp,
+                      &m->overflow_group, &m->group_leaves, &m->group_leaf_count};
     for (DevBuf* b : bufs) b->release();
     m->totals.release();
     if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
@@ -932,9 +960,9 @@ namespace tkd {
 
 template <int EPL>
 static void launch_wave(tkhip_map* m, const QueryView& qv, const int32_t* list, const int32_t* list_count,
-                        int64_t nq, int64_t work_hint, const GatherOut& out) {
+                        int64_t nq, int64_t work_hint, const GatherOut& out, const GroupLeaves& gl) {
     int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(work_hint, 4), 1), 256 * 16);
-    k_gather_wave<EPL><<<blocks, 256, 0, m->stream>>>(m->view(), qv, list, list_count, nq, out);
+    k_gather_wave<EPL><<<blocks, 256, 0, m->stream>>>(m->view(), qv, list, list_count, nq, out, gl);
 }
 
 int map_reserve_queries(tkhip_map* m, int64_t nq) {
@@ -943,6 +971,9 @@ int map_reserve_queries(tkhip_map* m, int64_t nq) {
     TK_TRY(m->q_vals_a.ensure((size_t)nq * 4));
     TK_TRY(m->q_order.ensure((size_t)nq * 4));
     TK_TRY(m->overflow.ensure((size_t)nq * 4));
+    TK_TRY(m->overflow_group.ensure((size_t)nq * 4));
+    TK_TRY(m->group_leaves.ensure((size_t)((nq + 63) / 64) * kMaxGroupLeaves * 4));
+    TK_TRY(m->group_leaf_count.ensure((size_t)((nq + 63) / 64) * 4));
     TK_TRY(sort_pairs_u32_reserve(m->prim_temp, (size_t)nq, 30));
     return TKHIP_OK;
 }
@@ -964,15 +995,15 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
     hipStream_t s = m->stream;
     const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
-    auto wave_all = [&](const int32_t* list, const int32_t* cnt, int64_t hint) {
-        if (epl == 2) launch_wave<2>(m, qv, list, cnt, nq, hint, out);
-        else if (epl == 4) launch_wave<4>(m, qv, list, cnt, nq, hint, out);
-        else launch_wave<8>(m, qv, list, cnt, nq, hint, out);
+    auto wave_all = [&](const int32_t* list, const int32_t* cnt, int64_t hint, const GroupLeaves& gl) {
+        if (epl == 2) launch_wave<2>(m, qv, list, cnt, nq, hint, out, gl);
+        else if (epl == 4) launch_wave<4>(m, qv, list, cnt, nq, hint, out, gl);
+        else launch_wave<8>(m, qv, list, cnt, nq, hint, out, gl);
     };
     m->last_group_ms = 0.f;
     m->last_overflow = 0;
     if (mode == 1) {
-        wave_all(nullptr, nullptr, nq);
+        wave_all(nullptr, nullptr, nq, GroupLeaves{nullptr, nullptr, nullptr});
         TK_LAUNCH_CHECK();
         return TKHIP_OK;
     }
@@ -988,13 +1019,14 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     TK_TRY(map_flush_timing(m));
     TK_HIP(hipEventRecord(m->ev_begin, s));
     const int64_t groups = (nq + 63) / 64;
+    const GroupLeaves gl{m->overflow_group.as<int32_t>(), m->group_leaves.as<int32_t>(), m->group_leaf_count.as<int32_t>()};
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), 256 * 32);
     if (out.idx)
         k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
-                                                    m->overflow.as<int32_t>(), ocount);
+                                                    m->overflow.as<int32_t>(), ocount, gl);
     else
         k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
-                                                     m->overflow.as<int32_t>(), ocount);
+                                                     m->overflow.as<int32_t>(), ocount, gl);
     TK_LAUNCH_CHECK();
     TK_HIP(hipEventRecord(m->ev_end, s));
     m->ev_pending = true;
@@ -1003,7 +1035,7 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         TK_HIP(hipEventSynchronize(m->ev_end));
         TK_HIP(hipEventElapsedTime(&m->last_group_ms, m->ev_begin, m->ev_end));
     }
-    wave_all(m->overflow.as<int32_t>(), ocount, nq);
+    wave_all(m->overflow.as<int32_t>(), ocount, nq, gl);
     TK_LAUNCH_CHECK();
     if (timed) {
         int32_t oc = 0;
