@@ -90,6 +90,10 @@ struct SppmState {
     int64_t n_slots = 0;
     Lane lane[3];
     int photon_loads = 3;            // see photon_launch_batch
+    // world > 1: sixteenths of the GPU's wave slots the path kernel of each lane takes.  The three run side
+    // by side from the start (whole grids of each would queue up behind one another) and one sixteenth
+    // stays free for the small kernels between the passes; measured at rank 0 of 2: 4.55 -> 3.6 ms.
+    int share[3] = {2, 3, 10};
     int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
     DevBuf qbuf[2];
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
@@ -753,9 +757,9 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     // (197 -> 208 iterations/s against a fixed 2; at 7 the caustic pass would be the longest chain).
     int64_t want = divup(B, kPathBlock);
     if (ln.queued_last >= 0) want = std::max<int64_t>(divup(ln.queued_last * B / std::max<int64_t>(ln.batch_last, 1), s->photon_loads * kPathBlock), 256);
-    // A rank of several traces a share of the paths and leaves much of its GPU idle: there the
-    // full grid, over which the kernel spreads the queue thinly, is the faster shape.
-    const int waves = s->world > 1 ? s->path_waves[KIND] : (int)std::min<int64_t>(want, s->path_waves[KIND]);
+    // A rank of several traces a share of the paths and leaves much of its GPU idle: there a fixed
+    // share of the wave slots, over which the kernel spreads the queue thinly, is the faster shape.
+    const int waves = s->world > 1 ? std::max(s->path_waves[KIND] * s->share[KIND] / 16, 64) : (int)std::min<int64_t>(want, s->path_waves[KIND]);
     k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
@@ -859,7 +863,7 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
     TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
     k_camera_first<<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
-    const int waves = s->world > 1 ? s->path_waves[2] : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
+    const int waves = s->world > 1 ? std::max(s->path_waves[2] * s->share[2] / 16, 64) : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
     k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(ln.h_counters, counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
@@ -1052,6 +1056,7 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
             set_error("tkhip_sppm_begin: occupancy query failed");
             rc = TKHIP_E_HIP;
         } else {
+            if (const char* sv = getenv("TKHIP_SHARE")) sscanf(sv, "%d %d %d", &s->share[0], &s->share[1], &s->share[2]);   // tuning aid
             const char* ov = getenv("TKHIP_PATH_WAVES_PER_CU");   // tuning aid
             for (int l = 0; l < 3; ++l) {
                 if (ov && atoi(ov) > 0) per_cu[l] = atoi(ov);

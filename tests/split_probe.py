@@ -10,7 +10,7 @@ from pathtracer_amd.scene import Scene, asset_scene
 D._all_gather = lambda t, world: [t] * world
 scene = Scene.load(asset_scene("cornell_dragon.scene"))
 param = scene.sppm_param()
-for world in (1, 2, 4, 8):
+for world in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
     be = D.HipBackend(scene, param, 20, 0.8, 0x5EED, 1024, 1024, 0, world, 0)
     if world == 1:
         be_step = lambda it: be.iteration_single(it)
