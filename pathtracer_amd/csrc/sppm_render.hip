@@ -1128,8 +1128,8 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
         for (int w = 0; w < 2; ++w) {
             Lane& ln = s->lane[w];
             if (s->quota[w] <= 0) continue;
-            TK_HIP(hipMemsetAsync(ln.rec_count.p, 0, 1024 * 4, ln.stream));
-            TK_TRY(exclusive_scan_i32(ln.stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), 1024));
+            TK_HIP(hipMemsetAsync(ln.rec_count.p, 0, 256 * 4, ln.stream));   // the staging holds at least 256 paths
+            TK_TRY(exclusive_scan_i32(ln.stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), 256));
             tkhip_map* m = s->map[w];
             if (m->cap >= 2048) {
                 TK_HIP(hipMemsetAsync(m->key_a.p, 0, 2048 * 4, m->stream));

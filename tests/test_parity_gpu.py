@@ -233,6 +233,21 @@ def test_photon_begin_state_checks():
     be.close()
 
 
+def test_tiny_photon_maps_render():
+    """Photon maps far smaller than any staging or scratch granule (100 + 10 photons, k larger than the maps)."""
+    from pathtracer_amd import distributed as D
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    prm = scene.sppm_param(globalSize=100, causticSize=10, numRecurse=4)
+    be = D.HipBackend(scene, prm, 20, 0.8, 0x5EED, 24, 24, 0, 1, 0)
+    for it in range(3):
+        st = _abi.TkIterStats()
+        be.iteration_single(it, st)
+        assert st.global_stored == 100 and st.caustic_stored == 10 and st.gathers_global > 0
+    planes = be.export_planes().cpu().numpy()
+    assert np.isfinite(planes).all()
+    be.close()
+
+
 def test_knn_edge_cases(gpu_ctx):
     rng = np.random.default_rng(8)
     qp, qn, qwo, qR, r2 = make_queries(rng, 130)
