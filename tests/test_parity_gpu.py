@@ -483,17 +483,18 @@ def test_dragon_iteration_statistics(dragon_scene):
     tr.close(); orr.close(); osc.close()
 
 
-def test_two_rank_sharding_on_one_gpu():
-    """rank 0 and rank 1 of a world of 2 as two contexts on this GPU, exchange by hand: the merged pixel state
-    equals the oracle's for the same sharding up to the usual divergent paths."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_sharding_on_one_gpu(world):
+    """Every rank of a world of 2 (3: quotas with a remainder) as a context of its own on this GPU, exchange by hand:
+    the merged pixel state equals the oracle's for the same sharding up to the usual divergent paths."""
     import torch
     from pathtracer_amd import distributed as D
     scene = Scene.load(asset_scene("cornell_sphere.scene"))
     W, GS, CS = 64, 8000, 1000
     prm = scene.sppm_param(globalSize=GS, causticSize=CS, numRecurse=4)
-    bes = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, 2, 0) for r in range(2)]
+    bes = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, world, 0) for r in range(world)]
     osc = O.OracleScene(scene, W, W)
-    ors = [O.OracleSppm(osc, prm, 20, 0.8, 0x5EED, rank=r, world=2, threads=4) for r in range(2)]
+    ors = [O.OracleSppm(osc, prm, 20, 0.8, 0x5EED, rank=r, world=world, threads=4) for r in range(world)]
     for it in range(2):
         for be, orc in zip(bes, ors):
             be.photon_begin(it)        # light paths enqueued first, camera paths traced beside them,
@@ -502,7 +503,7 @@ def test_two_rank_sharding_on_one_gpu():
             orc.photon_pass(it)
         for which, size in ((0, GS), (1, CS)):
             parts = [be.export_local(which) for be in bes]
-            assert [p[3] for p in parts] == [D.quota(size, r, 2) for r in range(2)]
+            assert [p[3] for p in parts] == [D.quota(size, r, world) for r in range(world)]
             cat = [torch.cat([p[i][:p[3]] for p in parts]).contiguous() for i in range(3)]
             shot = sum(p[4] for p in parts)
             for be in bes:
@@ -518,8 +519,8 @@ def test_two_rank_sharding_on_one_gpu():
             orc.build_maps(); orc.camera_pass(it)
     planes = [be.export_planes().cpu().numpy() for be in bes]
     oplanes = [o.pixels().T.reshape(13, W, W) for o in ors]
-    owner = np.array([D.row_owner(y, 2) for y in range(W)])
-    for r in range(2):
+    owner = np.array([D.row_owner(y, world) for y in range(W)])
+    for r in range(world):
         mine, other = owner == r, owner != r
         assert (planes[r][:11, other] == 0).all() and (planes[r][11:, other] == np.float32(0.08)).all()
         a, b = planes[r][:, mine], oplanes[r][:, mine]
@@ -527,7 +528,8 @@ def test_two_rank_sharding_on_one_gpu():
         assert ok.mean() > 0.95
     # import / export round trip and resolve on the merged state
     merged = planes[0].copy()
-    merged[:, owner == 1] = planes[1][:, owner == 1]
+    for r in range(1, world):
+        merged[:, owner == r] = planes[r][:, owner == r]
     bes[0].import_planes(torch.from_numpy(merged).cuda())
     assert np.array_equal(bes[0].export_planes().cpu().numpy(), merged)
     img = bes[0].resolve()
