@@ -7,8 +7,11 @@
 // 64-byte nodes that carry both child boxes, leaves of up to four primitives
 // referenced straight from the parent, primitives reordered into leaf order.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
+#include <system_error>
+#include <thread>
 
 #include "tk_common.h"
 
@@ -46,19 +49,23 @@ struct TmpNode {
     int32_t first = 0, count = 0;    // leaf: slot range
 };
 
+// The two halves of a large range are built by two threads.  The result does not depend on how the
+// threads interleave: a range of primitives only ever moves within itself, a leaf's slots are the
+// positions of its range, and the final node numbers come from a walk of the finished tree.
+constexpr int kTaskPrims = 4096;   // smaller ranges stay on the thread that reached them
+constexpr int kTaskDepth = 4;      // at most 2^4 threads
+
 struct Builder {
     std::vector<Prim> prims;
-    std::vector<TmpNode> nodes;
-    std::vector<int32_t> order;
+    std::vector<TmpNode> nodes;          // 2n slots, handed out by next_node
+    std::atomic<int32_t> next_node{0};
     int max_leaf = 4;
     int depth_limit = 32;
     bool median_only = false;
-    int max_depth = 0;
+    std::atomic<int> max_depth{0};
 
     int32_t build(int start, int end, int depth) {
-        int32_t me = int32_t(nodes.size());
-        nodes.emplace_back();
-        max_depth = std::max(max_depth, depth);
+        int32_t me = next_node.fetch_add(1, std::memory_order_relaxed);
         Box b, cb;
         b.reset();
         cb.reset();
@@ -66,9 +73,10 @@ struct Builder {
         nodes[me].b = b;
         int n = end - start;
         auto make_leaf = [&]() {
-            nodes[me].first = int32_t(order.size());
+            nodes[me].first = start;
             nodes[me].count = n;
-            for (int i = start; i < end; ++i) order.push_back(prims[i].id);
+            int seen = max_depth.load(std::memory_order_relaxed);
+            while (depth > seen && !max_depth.compare_exchange_weak(seen, depth, std::memory_order_relaxed)) {}
             return me;
         };
         if (n == 1) return make_leaf();
@@ -126,8 +134,21 @@ struct Builder {
             std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
                              [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis]; });
         }
-        int32_t l = build(start, mid, depth + 1);
-        int32_t r = build(mid, end, depth + 1);
+        int32_t l = -1, r = -1;
+        bool forked = false;
+        if (n >= kTaskPrims && depth < kTaskDepth) {
+            try {
+                std::thread other([&]() { l = build(start, mid, depth + 1); });
+                forked = true;
+                r = build(mid, end, depth + 1);
+                other.join();
+            } catch (const std::system_error&) {   // no thread to be had: carry on alone
+            }
+        }
+        if (!forked) {
+            l = build(start, mid, depth + 1);
+            r = build(mid, end, depth + 1);
+        }
         nodes[me].left = l;
         nodes[me].right = r;
         return me;
@@ -149,38 +170,40 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
     Builder bld;
     bld.max_leaf = std::min(max_leaf, 8);
     bld.prims.resize(size_t(n));
-    for (int i = 0; i < n_tris; ++i) {
-        Prim& p = bld.prims[size_t(i)];
-        p.b.reset();
-        p.b.grow(tris[i].v0);
-        p.b.grow(tris[i].v1);
-        p.b.grow(tris[i].v2);
-        p.id = i;
-    }
-    for (int j = 0; j < n_spheres; ++j) {
-        Prim& p = bld.prims[size_t(n_tris + j)];
-        // pad by a few ulps: the hit point is re-projected onto the sphere
-        float r = spheres[j].radius * 1.00001f;
-        for (int a = 0; a < 3; ++a) { p.b.mn[a] = spheres[j].center[a] - r; p.b.mx[a] = spheres[j].center[a] + r; }
-        p.id = n_tris + j;
-    }
-    for (auto& p : bld.prims)
-        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.b.mn[a] + 0.5f * p.b.mx[a];
-    std::vector<Prim> saved = bld.prims;
+    bld.nodes.resize(size_t(n) * 2);
+    auto fill_prims = [&]() {
+        for (int i = 0; i < n_tris; ++i) {
+            Prim& p = bld.prims[size_t(i)];
+            p.b.reset();
+            p.b.grow(tris[i].v0);
+            p.b.grow(tris[i].v1);
+            p.b.grow(tris[i].v2);
+            p.id = i;
+        }
+        for (int j = 0; j < n_spheres; ++j) {
+            Prim& p = bld.prims[size_t(n_tris + j)];
+            // pad by a few ulps: the hit point is re-projected onto the sphere
+            float r = spheres[j].radius * 1.00001f;
+            for (int a = 0; a < 3; ++a) { p.b.mn[a] = spheres[j].center[a] - r; p.b.mx[a] = spheres[j].center[a] + r; }
+            p.id = n_tris + j;
+        }
+        for (auto& p : bld.prims)
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.b.mn[a] + 0.5f * p.b.mx[a];
+    };
+    // a second attempt, with median splits only, if the SAH tree comes out too deep for the stack
     for (int attempt = 0; attempt < 2; ++attempt) {
-        bld.nodes.clear();
-        bld.order.clear();
+        fill_prims();
+        if (attempt == 1) std::fill(bld.nodes.begin(), bld.nodes.end(), TmpNode());
+        bld.next_node = 0;
         bld.max_depth = 0;
         bld.median_only = attempt == 1;
         bld.depth_limit = max_stack_depth - 6;
-        bld.nodes.reserve(size_t(n) * 2);
-        bld.order.reserve(size_t(n));
-        if (attempt == 1) bld.prims = saved;
         bld.build(0, n, 0);
         if (bld.max_depth < max_stack_depth - 1) break;
     }
     out->max_depth = bld.max_depth;
-    out->order = bld.order;
+    out->order.resize(size_t(n));
+    for (int i = 0; i < n; ++i) out->order[size_t(i)] = bld.prims[size_t(i)].id;
     const TmpNode& root = bld.nodes[0];
     for (int a = 0; a < 3; ++a) { out->bmin[a] = root.b.mn[a]; out->bmax[a] = root.b.mx[a]; }
     if (root.left < 0) {
@@ -197,6 +220,7 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
         return;
     }
     // number the interior nodes in depth-first order
+    bld.nodes.resize(size_t(bld.next_node.load()));
     std::vector<int32_t> flat(bld.nodes.size(), -1);
     int32_t count = 0;
     std::vector<int32_t> stack{0};

@@ -1,6 +1,7 @@
 // sppm_tracer.cpp — host-side tracer classes driving the device backend.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ray_tracer.h"
@@ -172,10 +173,36 @@ void SppmTracer::saveImage(std::string filename) {
     else fprintf(stderr, "FAILED\n");
 }
 
-// src/tracer/TkSppmTracer.cpp:447-544
+// The headless loop (src/tracer/TkSppmTracer.cpp:447-544).  Like the reference's
+// it neither tone-maps between iterations nor times their phases (that is what
+// rendering(), the step of the windowed path, does): the image is resolved once,
+// at the end.  TKHOST_ITER_STATS=1 in the environment switches to the timed,
+// previewed steps.
 void SppmTracer::render(std::string filename) {
     startRaytracing();
-    while (mState == RENDERING) rendering();
+    const char* want_stats = getenv("TKHOST_ITER_STATS");
+    if (want_stats && atoi(want_stats) != 0) {
+        while (mState == RENDERING) rendering();
+    } else {
+        int64_t shot[2] = {0, 0};
+        while (mState == RENDERING) {
+            if (tkhip_sppm_iteration(mCtx, curRecurse, nullptr) != 0) {
+                fail("tkhip_sppm_iteration");
+                mState = READY;
+                return;
+            }
+            int64_t total[2] = {0, 0};
+            tkhip_sppm_counters(mCtx, &total[0], &total[1], nullptr);
+            fprintf(stderr, "\r[Tracer] Iteration %d... 100%%  (shot %lld global, %lld caustic light paths)\n", curRecurse,
+                    (long long)(total[0] - shot[0]), (long long)(total[1] - shot[1]));
+            shot[0] = total[0];
+            shot[1] = total[1];
+            if (++curRecurse >= numRecurse) {
+                fprintf(stderr, "\r[Tracer] Rendering Done!\n");
+                mState = DONE;
+            }
+        }
+    }
     if (mState == DONE) saveImage(filename);
 }
 
