@@ -8,7 +8,10 @@
 // referenced straight from the parent, primitives reordered into leaf order.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <system_error>
 #include <thread>
@@ -52,8 +55,8 @@ struct TmpNode {
 // The two halves of a large range are built by two threads.  The result does not depend on how the
 // threads interleave: a range of primitives only ever moves within itself, a leaf's slots are the
 // positions of its range, and the final node numbers come from a walk of the finished tree.
-constexpr int kTaskPrims = 4096;   // smaller ranges stay on the thread that reached them
-constexpr int kTaskDepth = 4;      // at most 2^4 threads
+constexpr int kTaskPrims = 2048;   // a half smaller than this stays on the thread that reached it
+constexpr int kMaxThreads = 16;
 
 struct Builder {
     std::vector<Prim> prims;
@@ -63,6 +66,7 @@ struct Builder {
     int depth_limit = 32;
     bool median_only = false;
     std::atomic<int> max_depth{0};
+    std::atomic<int> threads{1};
 
     int32_t build(int start, int end, int depth) {
         int32_t me = next_node.fetch_add(1, std::memory_order_relaxed);
@@ -136,14 +140,17 @@ struct Builder {
         }
         int32_t l = -1, r = -1;
         bool forked = false;
-        if (n >= kTaskPrims && depth < kTaskDepth) {
-            try {
-                std::thread other([&]() { l = build(start, mid, depth + 1); });
-                forked = true;
-                r = build(mid, end, depth + 1);
-                other.join();
-            } catch (const std::system_error&) {   // no thread to be had: carry on alone
+        if (std::min(mid - start, end - mid) >= kTaskPrims) {
+            if (threads.fetch_add(1, std::memory_order_relaxed) < kMaxThreads) {
+                try {
+                    std::thread other([&]() { l = build(start, mid, depth + 1); });
+                    forked = true;
+                    r = build(mid, end, depth + 1);
+                    other.join();
+                } catch (const std::system_error&) {   // no thread to be had: carry on alone
+                }
             }
+            threads.fetch_sub(1, std::memory_order_relaxed);
         }
         if (!forked) {
             l = build(start, mid, depth + 1);
@@ -167,28 +174,36 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
     for (int a = 0; a < 3; ++a) { out->bmin[a] = 0; out->bmax[a] = 0; }
     int n = n_tris + n_spheres;
     if (n == 0) return;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (getenv("TKHIP_VERBOSE"))
+            fprintf(stderr, "[tkhip] build_bvh: %s at %.1f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
     Builder bld;
     bld.max_leaf = std::min(max_leaf, 8);
     bld.prims.resize(size_t(n));
     bld.nodes.resize(size_t(n) * 2);
     auto fill_prims = [&]() {
-        for (int i = 0; i < n_tris; ++i) {
-            Prim& p = bld.prims[size_t(i)];
-            p.b.reset();
-            p.b.grow(tris[i].v0);
-            p.b.grow(tris[i].v1);
-            p.b.grow(tris[i].v2);
-            p.id = i;
-        }
+        host_parallel_for(size_t(n_tris), [&](size_t begin, size_t end) {
+            for (size_t i = begin; i < end; ++i) {
+                Prim& p = bld.prims[i];
+                p.b.reset();
+                p.b.grow(tris[i].v0);
+                p.b.grow(tris[i].v1);
+                p.b.grow(tris[i].v2);
+                p.id = int32_t(i);
+                for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.b.mn[a] + 0.5f * p.b.mx[a];
+            }
+        });
         for (int j = 0; j < n_spheres; ++j) {
             Prim& p = bld.prims[size_t(n_tris + j)];
             // pad by a few ulps: the hit point is re-projected onto the sphere
             float r = spheres[j].radius * 1.00001f;
             for (int a = 0; a < 3; ++a) { p.b.mn[a] = spheres[j].center[a] - r; p.b.mx[a] = spheres[j].center[a] + r; }
             p.id = n_tris + j;
-        }
-        for (auto& p : bld.prims)
             for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.b.mn[a] + 0.5f * p.b.mx[a];
+        }
     };
     // a second attempt, with median splits only, if the SAH tree comes out too deep for the stack
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -198,12 +213,16 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
         bld.max_depth = 0;
         bld.median_only = attempt == 1;
         bld.depth_limit = max_stack_depth - 6;
+        lap("boxes set up");
         bld.build(0, n, 0);
+        lap("tree built");
         if (bld.max_depth < max_stack_depth - 1) break;
     }
     out->max_depth = bld.max_depth;
     out->order.resize(size_t(n));
-    for (int i = 0; i < n; ++i) out->order[size_t(i)] = bld.prims[size_t(i)].id;
+    host_parallel_for(size_t(n), [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; ++i) out->order[i] = bld.prims[i].id;
+    });
     const TmpNode& root = bld.nodes[0];
     for (int a = 0; a < 3; ++a) { out->bmin[a] = root.b.mn[a]; out->bmax[a] = root.b.mx[a]; }
     if (root.left < 0) {
@@ -234,20 +253,23 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
         stack.push_back(tn.left);
     }
     out->nodes.resize(size_t(count));
-    for (size_t t = 0; t < bld.nodes.size(); ++t) {
-        if (flat[t] < 0) continue;
-        const TmpNode& tn = bld.nodes[t];
-        const TmpNode& L = bld.nodes[size_t(tn.left)];
-        const TmpNode& R = bld.nodes[size_t(tn.right)];
-        BvhNode& o = out->nodes[size_t(flat[t])];
-        for (int a = 0; a < 3; ++a) {
-            o.lmin[a] = L.b.mn[a]; o.lmax[a] = L.b.mx[a];
-            o.rmin[a] = R.b.mn[a]; o.rmax[a] = R.b.mx[a];
+    host_parallel_for(bld.nodes.size(), [&](size_t begin, size_t end) {
+        for (size_t t = begin; t < end; ++t) {
+            if (flat[t] < 0) continue;
+            const TmpNode& tn = bld.nodes[t];
+            const TmpNode& L = bld.nodes[size_t(tn.left)];
+            const TmpNode& R = bld.nodes[size_t(tn.right)];
+            BvhNode& o = out->nodes[size_t(flat[t])];
+            for (int a = 0; a < 3; ++a) {
+                o.lmin[a] = L.b.mn[a]; o.lmax[a] = L.b.mx[a];
+                o.rmin[a] = R.b.mn[a]; o.rmax[a] = R.b.mx[a];
+            }
+            o.left = L.left < 0 ? encode_leaf(L) : flat[size_t(tn.left)];
+            o.right = R.left < 0 ? encode_leaf(R) : flat[size_t(tn.right)];
+            o.pad0 = o.pad1 = 0;
         }
-        o.left = L.left < 0 ? encode_leaf(L) : flat[size_t(tn.left)];
-        o.right = R.left < 0 ? encode_leaf(R) : flat[size_t(tn.right)];
-        o.pad0 = o.pad1 = 0;
-    }
+    });
+    lap("nodes laid out");
 }
 
 }  // namespace tkd

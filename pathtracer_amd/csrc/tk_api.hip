@@ -1,7 +1,9 @@
 // tk_api.hip — context lifecycle, scene / camera upload and the small
 // kernel-level entry points of the C ABI (include/tkhip.h).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "photon_map.h"
 #include "tk_bvh_device.h"
@@ -153,44 +155,55 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
         TK_REQUIRE(materials[m].type == TK_DIFFUSE || materials[m].type == TK_MIRROR || materials[m].type == TK_GLASS,
                    TKHIP_E_ARG, "material %d: unsupported type %d", m, materials[m].type);
 
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (getenv("TKHIP_VERBOSE"))
+            fprintf(stderr, "[tkhip] set_scene: %s at %.1f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
     HostBvh bvh;
     build_bvh(tris, n_tris, spheres, n_spheres, kMaxLeaf, kStackDepth, &bvh);
+    lap("tree built");
     TK_REQUIRE(bvh.max_depth < kStackDepth - 1, TKHIP_E_LIMIT, "scene BVH depth %d exceeds the traversal stack", bvh.max_depth);
 
     const size_t nprim = (size_t)n_tris + n_spheres;
     std::vector<TriIsect> isect(nprim);
-    for (size_t s = 0; s < nprim; ++s) {
-        int id = bvh.order[s];
-        TriIsect& t = isect[s];
-        memset(&t, 0, sizeof(t));
-        t.prim = id;
-        if (id < n_tris) {
-            for (int a = 0; a < 3; ++a) {
-                t.v0[a] = tris[id].v0[a];
-                t.e1[a] = tris[id].v1[a] - tris[id].v0[a];   // src/Triangle.hpp:21-22
-                t.e2[a] = tris[id].v2[a] - tris[id].v0[a];
+    host_parallel_for(nprim, [&](size_t begin, size_t end) {
+        for (size_t s = begin; s < end; ++s) {
+            int id = bvh.order[s];
+            TriIsect& t = isect[s];
+            memset(&t, 0, sizeof(t));
+            t.prim = id;
+            if (id < n_tris) {
+                for (int a = 0; a < 3; ++a) {
+                    t.v0[a] = tris[id].v0[a];
+                    t.e1[a] = tris[id].v1[a] - tris[id].v0[a];   // src/Triangle.hpp:21-22
+                    t.e2[a] = tris[id].v2[a] - tris[id].v0[a];
+                }
             }
         }
-    }
+    });
     std::vector<TriShade> shade((size_t)std::max(n_tris, 1));
     std::vector<float> area((size_t)std::max(n_tris, 1), 0.f);
-    for (int i = 0; i < n_tris; ++i) {
-        TriShade& t = shade[(size_t)i];
-        float e1[3], e2[3];
-        for (int a = 0; a < 3; ++a) {
-            t.v0[a] = tris[i].v0[a]; t.v1[a] = tris[i].v1[a]; t.v2[a] = tris[i].v2[a];
-            e1[a] = tris[i].v1[a] - tris[i].v0[a];
-            e2[a] = tris[i].v2[a] - tris[i].v0[a];
+    host_parallel_for((size_t)n_tris, [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; ++i) {
+            TriShade& t = shade[(size_t)i];
+            float e1[3], e2[3];
+            for (int a = 0; a < 3; ++a) {
+                t.v0[a] = tris[i].v0[a]; t.v1[a] = tris[i].v1[a]; t.v2[a] = tris[i].v2[a];
+                e1[a] = tris[i].v1[a] - tris[i].v0[a];
+                e2[a] = tris[i].v2[a] - tris[i].v0[a];
+            }
+            // normal = normalize(e1 x e2), area = |e1 x e2| / 2 (src/Triangle.hpp:23-24, src/Vector.hpp:80-103)
+            float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            float mag2 = cx * cx + cy * cy + cz * cz;
+            if (mag2 > 0) {
+                float inv = 1 / sqrtf(mag2);
+                t.nx = cx * inv; t.ny = cy * inv; t.nz = cz * inv;
+            } else { t.nx = cx; t.ny = cy; t.nz = cz; }
+            area[(size_t)i] = sqrtf(cx * cx + cy * cy + cz * cz) * 0.5f;
         }
-        // normal = normalize(e1 x e2), area = |e1 x e2| / 2 (src/Triangle.hpp:23-24, src/Vector.hpp:80-103)
-        float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
-        float mag2 = cx * cx + cy * cy + cz * cz;
-        if (mag2 > 0) {
-            float inv = 1 / sqrtf(mag2);
-            t.nx = cx * inv; t.ny = cy * inv; t.nz = cz * inv;
-        } else { t.nx = cx; t.ny = cy; t.nz = cz; }
-        area[(size_t)i] = sqrtf(cx * cx + cy * cy + cz * cz) * 0.5f;
-    }
+    });
     std::vector<float4> sph((size_t)std::max(n_spheres, 1));
     for (int j = 0; j < n_spheres; ++j)
         sph[(size_t)j] = make_float4(spheres[j].center[0], spheres[j].center[1], spheres[j].center[2], spheres[j].radius);
@@ -222,6 +235,7 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     }
     std::vector<TkMaterial> mats(materials, materials + n_materials);
     ctx->h_mats = mats;
+    lap("arrays laid out");
     hipStream_t s = ctx->stream;
     TK_TRY(upload(ctx->b_nodes, bvh.nodes, s));
     TK_TRY(upload(ctx->b_tri_isect, isect, s));
@@ -232,6 +246,7 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     TK_TRY(upload(ctx->b_lights, dl, s));
     TK_TRY(upload(ctx->b_cdf, cdf, s));
     TK_HIP(hipStreamSynchronize(s));
+    lap("uploaded");
     DScene& sc = ctx->scene;
     sc.nodes = ctx->b_nodes.as<BvhNode>();
     sc.tri_isect = ctx->b_tri_isect.as<TriIsect>();

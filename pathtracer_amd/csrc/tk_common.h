@@ -7,7 +7,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "tkhip.h"
@@ -138,6 +141,30 @@ struct HostBvh {
 // Builds the flat two-children-per-node BVH over triangles followed by spheres.
 void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int n_spheres,
                int max_leaf, int max_stack_depth, HostBvh* out);
+
+// fn(begin, end) over [0, n) in contiguous pieces on up to 16 host threads; small n runs on the caller.
+template <class F>
+void host_parallel_for(size_t n, F fn) {
+    constexpr size_t kPiece = 65536;
+    size_t pieces = std::min<size_t>((n + kPiece - 1) / kPiece, 16);
+    if (pieces <= 1) {
+        fn(size_t(0), n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    size_t done = 0;
+    for (size_t t = 0; t + 1 < pieces; ++t) {
+        size_t end = n * (t + 1) / pieces;
+        try {
+            pool.emplace_back([=]() { fn(done, end); });
+        } catch (const std::system_error&) {   // no thread to be had: the caller takes the rest
+            break;
+        }
+        done = end;
+    }
+    fn(done, n);
+    for (auto& t : pool) t.join();
+}
 
 struct SppmState;
 
