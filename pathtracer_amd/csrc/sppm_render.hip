@@ -133,7 +133,7 @@ struct SppmState {
     int n_rows = 0;
     int64_t n_slots = 0;
     Lane lane[3];
-    int photon_loads = 3;            // see photon_launch_batch
+    int photon_loads = 5;            // see photon_launch_batch
     // world > 1: sixteenths of the GPU's wave slots the path kernel of each lane takes.  The three run side
     // by side from the start (whole grids of each would queue up behind one another) and one sixteenth
     // stays free for the small kernels between the passes; measured at rank 0 of 2: 4.55 -> 3.6 ms.
@@ -1347,7 +1347,9 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         // sets the iteration, and wave slots move from the one to the other through photon_loads
         const double photon_done = std::max(t_photon_end[0] + build_ms[0], t_photon_end[1] + build_ms[1]) - t0;
         const double camera_done = t_cam - t0;
-        if (photon_done > 1.05 * camera_done) s->photon_loads = std::max(1, s->photon_loads - 1);
+        // (not in the first two iterations, whose photon chains run late for reasons of their own)
+        if (iter < 2) {}
+        else if (photon_done > 1.05 * camera_done) s->photon_loads = std::max(1, s->photon_loads - 1);
         else if (photon_done < 0.95 * camera_done) s->photon_loads = std::min(8, s->photon_loads + 1);
         static const bool verbose = getenv("TKHIP_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "tkhip: iteration %d: maps ready %.2f ms, queries ready %.2f ms -> photon_loads %d\n", iter, photon_done, camera_done, s->photon_loads);
