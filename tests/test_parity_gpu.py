@@ -564,3 +564,10 @@ def test_cpp_host_cli_renders_the_same_image(tmp_path):
     img = tr.render()
     assert np.array_equal(cli, img)
     tr.close()
+    # the timed, previewed steps of the windowed path render the same image as the headless loop
+    out2 = tmp_path / "cli_steps.ppm"
+    res = subprocess.run([exe, str(sf), "--width", "80", "--height", "80", "--out", str(out2)], capture_output=True, text=True,
+                         timeout=300, env=dict(os.environ, TKHOST_ITER_STATS="1"))
+    assert res.returncode == 0, res.stderr
+    assert "Shoot global photons" in res.stderr
+    assert out2.read_bytes() == data
