@@ -63,17 +63,23 @@ class HipBackend:
     def photon_pass(self, it, stats=None):
         self.tracer.photon_pass(it, stats)
 
+    def export_local_into(self, which, pos, power, direction):
+        """This rank's photons of one map into caller-owned device arrays ((cap, 3) float32 twice, (cap,) int16,
+        rows past the photon count left as they are); returns (count, light paths shot)."""
+        n, shot = C.c_int64(), C.c_int64()
+        torch.cuda.current_stream(self.dev).synchronize()   # torch's work on these buffers, not the lanes of the library
+        check(self.lib, self.lib.tkhip_sppm_export_local_photons(self.h, which, pos.data_ptr(), power.data_ptr(),
+                                                                 direction.data_ptr(), pos.shape[0], C.byref(n), C.byref(shot)),
+              "tkhip_sppm_export_local_photons")
+        return n.value, shot.value
+
     def export_local(self, which):
         cap = max(self.max_quota[which], 1)
         pos = torch.zeros((cap, 3), dtype=torch.float32, device=self.dev)
         power = torch.zeros((cap, 3), dtype=torch.float32, device=self.dev)
         direction = torch.zeros((cap,), dtype=torch.int16, device=self.dev)
-        n, shot = C.c_int64(), C.c_int64()
-        torch.cuda.current_stream(self.dev).synchronize()   # torch's work on these buffers, not the lanes of the library
-        check(self.lib, self.lib.tkhip_sppm_export_local_photons(self.h, which, pos.data_ptr(), power.data_ptr(),
-                                                                 direction.data_ptr(), cap, C.byref(n), C.byref(shot)),
-              "tkhip_sppm_export_local_photons")
-        return pos, power, direction, n.value, shot.value
+        n, shot = self.export_local_into(which, pos, power, direction)
+        return pos, power, direction, n, shot
 
     def set_map(self, which, pos, power, direction, n, shot_total):
         torch.cuda.current_stream(self.dev).synchronize()   # torch's work on these buffers, not the lanes of the library
@@ -127,39 +133,68 @@ def _all_gather(t, world):
     return parts
 
 
+def _exchange_layout(caps):
+    """Word offsets inside one rank's exchange buffer (int32 words): 8 header words, then per map the
+    positions (3 words per photon), the powers (3) and the direction pairs (2 bytes per photon, padded to
+    whole words).  Returns ([(positions, powers, directions, direction words, capacity)] per map, total)."""
+    off, lay = 8, []
+    for cap in caps:
+        dwords = (cap + 1) // 2
+        lay.append((off, off + 3 * cap, off + 6 * cap, dwords, cap))
+        off += 6 * cap + dwords
+    return lay, off
+
+
 def exchange_photons(backend, world):
     """All-gather of both maps' photons and sum of their shot counters, as ONE collective per iteration: each
-    rank sends an int32 table of 7 columns (position and power bit-cast, the two direction bytes) with a
-    header row (photon counts and shot counters of both maps).  Returns [(n_total, shot_total)] per map."""
+    rank sends one flat int32 buffer (neither RCCL nor gloo gathers int16), a header (photon counts and shot
+    counters of both maps) followed by the bit-cast arrays of both maps.  A backend with `export_local_into`
+    writes its photons straight into that buffer.  Returns [(n_total, shot_total)] per map."""
     if world == 1:
         return [None, None]   # a single rank installs its own photons at the end of its photon pass
-    parts = [backend.export_local(which) for which in (0, 1)]
-    caps = [p[0].shape[0] for p in parts]
-    dev = parts[0][0].device
-    table = torch.zeros((1 + caps[0] + caps[1], 7), dtype=torch.int32, device=dev)
+    direct = hasattr(backend, "export_local_into")
+    if direct:
+        caps = [max(q, 1) for q in backend.max_quota]
+        dev = backend.dev
+        parts = None
+    else:
+        parts = [backend.export_local(which) for which in (0, 1)]
+        caps = [p[0].shape[0] for p in parts]
+        dev = parts[0][0].device
+    lay, total = _exchange_layout(caps)
+    flat = getattr(backend, "_exchange_buffer", None)   # reused every iteration: what is read of it is rewritten
+    if flat is None or flat.numel() != total or flat.device != dev:
+        flat = torch.zeros((total,), dtype=torch.int32, device=dev)
+        try:
+            backend._exchange_buffer = flat
+        except AttributeError:
+            pass
     head = []
-    for pos, power, direction, n, shot in parts:
+    for which, (o_pos, o_pow, o_dir, dwords, cap) in enumerate(lay):
+        pos = flat[o_pos:o_pos + 3 * cap].view(torch.float32).view(cap, 3)
+        power = flat[o_pow:o_pow + 3 * cap].view(torch.float32).view(cap, 3)
+        direction = flat[o_dir:o_dir + dwords].view(torch.int16)[:cap]
+        if direct:
+            n, shot = backend.export_local_into(which, pos, power, direction)
+        else:
+            pos.copy_(parts[which][0])
+            power.copy_(parts[which][1])
+            direction.copy_(parts[which][2])
+            n, shot = parts[which][3], parts[which][4]
         head += [n, shot & 0x7FFFFFFF, shot >> 31]
-    table[0, :6] = torch.tensor(head, dtype=torch.int32)
-    row = 1
-    for (pos, power, direction, n, shot), cap in zip(parts, caps):
-        table[row:row + cap, 0:3] = pos.contiguous().view(torch.int32)
-        table[row:row + cap, 3:6] = power.contiguous().view(torch.int32)
-        table[row:row + cap, 6] = direction.to(torch.int32)   # neither RCCL nor gloo gathers int16
-        row += cap
-    tables = _all_gather(table, world)
-    heads = torch.stack([t[0, :6] for t in tables]).cpu().tolist()
+    flat[:6] = torch.tensor(head, dtype=torch.int32)
+    flats = _all_gather(flat, world)
+    heads = torch.stack([t[:6] for t in flats]).cpu().tolist()
     totals = []
-    row = 1
-    for which, cap in enumerate(caps):
+    for which, (o_pos, o_pow, o_dir, dwords, cap) in enumerate(lay):
         counts = [int(h[3 * which]) for h in heads]
         shot_total = sum(int(h[3 * which + 1]) + (int(h[3 * which + 2]) << 31) for h in heads)
-        rows = torch.cat([t[row:row + c] for t, c in zip(tables, counts)], dim=0)
         n_total = sum(counts)
-        backend.set_map(which, rows[:, 0:3].contiguous().view(torch.float32), rows[:, 3:6].contiguous().view(torch.float32),
-                        rows[:, 6].to(torch.int16).contiguous(), n_total, shot_total)
+        pos = torch.cat([t[o_pos:o_pos + 3 * c] for t, c in zip(flats, counts)]).view(torch.float32).view(-1, 3)
+        power = torch.cat([t[o_pow:o_pow + 3 * c] for t, c in zip(flats, counts)]).view(torch.float32).view(-1, 3)
+        direction = torch.cat([t[o_dir:o_dir + dwords].view(torch.int16)[:c] for t, c in zip(flats, counts)])
+        backend.set_map(which, pos, power, direction, n_total, shot_total)
         totals.append((n_total, shot_total))
-        row += cap
     return totals
 
 

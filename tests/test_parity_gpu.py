@@ -541,6 +541,50 @@ def test_rank_sharding_on_one_gpu(world):
     osc.close()
 
 
+def test_photon_exchange_buffer_on_one_gpu(monkeypatch):
+    """The one-collective photon exchange of the multi-rank driver (flat buffer, photons exported straight into
+    it) against the exchange by hand, for a world of 3 whose quotas leave a remainder; the all-gather is played
+    by handing every rank's buffer to rank 0."""
+    import torch
+    from pathtracer_amd import distributed as D
+    world = 3
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    W, GS, CS = 32, 8000, 1000
+    prm = scene.sppm_param(globalSize=GS, causticSize=CS, numRecurse=4)
+    bes = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, world, 0) for r in range(world)]
+    for be in bes:
+        be.photon_pass(0)
+    hand = []
+    for which in (0, 1):
+        parts = [be.export_local(which) for be in bes]
+        hand.append(([torch.cat([p[i][:p[3]] for p in parts]).cpu().numpy() for i in range(3)], sum(p[4] for p in parts)))
+    class Recorded(Exception):
+        pass
+
+    sent = {}
+    for r, be in enumerate(bes):
+        def record(t, w, r=r):
+            sent[r] = t.clone()
+            raise Recorded()
+        monkeypatch.setattr(D, "_all_gather", record)
+        with pytest.raises(Recorded):
+            D.exchange_photons(be, world)
+    assert len({int(t.numel()) for t in sent.values()}) == 1        # equal sizes: one plain all-gather
+    monkeypatch.setattr(D, "_all_gather", lambda t, w: [sent[r] for r in range(w)])
+    totals = D.exchange_photons(bes[0], world)
+    for which, size in ((0, GS), (1, CS)):
+        (pos, power, direction), shot = hand[which]
+        assert totals[which] == (size, shot)
+        gp, gw, th, ph = bes[0].tracer.photons(which)
+        assert np.array_equal(gp, pos) and np.array_equal(gw, power)
+        assert np.array_equal(th.astype(np.uint16) | (ph.astype(np.uint16) << 8), direction.view(np.uint16))
+    bes[0].build_maps()
+    bes[0].camera_pass(0)
+    assert bes[0].resolve().mean() > 1
+    for be in bes:
+        be.close()
+
+
 def test_cpp_host_cli_renders_the_same_image(tmp_path):
     """The C++ host program (loader + SppmTracer class over the C ABI) against the Python-driven render."""
     scene_text = open(asset_scene("cornell_sphere.scene")).read()
