@@ -250,6 +250,13 @@ int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset);
  * each other (src/tracer/TkSppmTracer.cpp:411-421, :480-496). */
 int tkhip_sppm_photon_begin(tkhip_ctx* ctx, int iter);
 
+/* The camera sampler of the render: jitter 1 (default) jitters inside the
+ * strata, jitter 0 takes the stratum centres, the reference's
+ * StratifiedSampler(x, y, jitter = false) (src/core/sampler.h:37-46,
+ * src/core/sampler.cpp:51, :61-62).  With jitter 0 nothing random is left in a
+ * camera pass. */
+int tkhip_sppm_set_jitter(tkhip_ctx* ctx, int jitter);
+
 /* Starts the camera paths of iteration `iter` (the part of traceTile that does
  * not read the photon maps, src/tracer/TkSppmTracer.cpp:296-321, :341-371) and
  * returns at once; tkhip_sppm_camera_pass(iter) then picks them up.  Optional:
@@ -352,6 +359,29 @@ int tkhip_pixel_update(tkhip_ctx* ctx, int64_t n, float* flux, float* photons, f
  * (src/core/TkLowdiscrepancy.h:19-32).  Host arrays. */
 int tkhip_radical_inverse(tkhip_ctx* ctx, int64_t n, const int32_t* dim, const uint64_t* index,
                           float* out);
+
+/* StratifiedSampler::get1D / get2D (src/core/sampler.cpp:40-64, with Hash,
+ * src/TkHash.h:111-119, and Math::PermutationElement, src/TkMath.h:206-234) for
+ * n (pixel, sample index) pairs with xs*ys strata each: every pair calls
+ * startPixelSample(pixel, index) and then makes the n_draws draws listed in
+ * `draws` (1 = get1D, 2 = get2D).  jitter 0 is the reference's jitter = false
+ * (stratum centres); otherwise the jitter comes from the counter-based generator
+ * keyed by seed.  out holds sum(draws) floats per pair.  Host arrays. */
+int tkhip_stratified_samples(tkhip_ctx* ctx, int64_t n, const int32_t* px, const int32_t* py,
+                             const int32_t* sample_idx, const int32_t* xs, const int32_t* ys, int n_draws,
+                             const uint8_t* draws, int jitter, uint64_t seed, float* out);
+
+/* Intersection::spawnRay(w) and Intersection::spawnRayTo(target)
+ * (src/Intersection.hpp:25-38) with offsetRayOrigin (src/Ray.hpp:43-57) for n
+ * surface points (p, pError, n): org = origin of the ray along w, org_to /
+ * dir_to = origin and direction of the ray towards target.  Host arrays, 3
+ * floats per entry. */
+int tkhip_spawn_rays(tkhip_ctx* ctx, int64_t n, const float* p, const float* perr, const float* nrm,
+                     const float* w, const float* target, float* org, float* org_to, float* dir_to);
+
+/* The two direction bytes a photon is stored with, for n world-space
+ * directions wo (src/tracer/TkSppmTracer.cpp:135-140, :193-198).  Host arrays. */
+int tkhip_encode_directions(tkhip_ctx* ctx, int64_t n, const float* wo, uint8_t* theta, uint8_t* phi);
 
 /* Camera::generateRay for n raster positions (src/core/camera.cpp:51-71).
  * Host arrays: raster float[2n] -> org float[3n], dir float[3n]. */

@@ -59,6 +59,7 @@ def lib():
         "orc_sppm_begin": (C.c_void_p, [C.c_void_p, C.POINTER(_abi.TkSppmParam), C.c_int, C.c_float, C.c_uint64,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "orc_sppm_destroy": (None, [C.c_void_p]),
+        "orc_sppm_set_jitter": (None, [C.c_void_p, C.c_int]),
         "orc_sppm_photon_pass": (None, [C.c_void_p, C.c_int, C.POINTER(_abi.TkIterStats)]),
         "orc_sppm_build_maps": (None, [C.c_void_p, C.POINTER(_abi.TkIterStats)]),
         "orc_sppm_camera_pass": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_abi.TkIterStats)]),
@@ -182,6 +183,9 @@ class OracleSppm:
         if self.h:
             lib().orc_sppm_destroy(self.h)
             self.h = None
+
+    def set_jitter(self, on):
+        lib().orc_sppm_set_jitter(self.h, 1 if on else 0)
 
     def photon_pass(self, it):
         st = _abi.TkIterStats()

@@ -194,8 +194,16 @@ int32_t orc_permutation_element(uint32_t i, uint32_t l, uint32_t p) {
 }
 
 /* ------------------------------------------------------------- sampling */
-/* src/core/sampling.cpp:60-77.  Unqualified cos/sin on a float argument bind
- * to the double C functions there; the product is rounded to float once. */
+/* Correctly rounded float sine / cosine / arc functions: the double function,
+ * rounded to float.  The reference's unqualified cos / sin / acos / atan2 on
+ * float arguments resolve to the float overloads (MSVC, and g++ once <math.h> is
+ * included); a float libm's last bit differs from platform to platform, this
+ * form gives the same value on the host and on the GPU. */
+static inline float tk_cosf(float x) { return (float)cos((double)x); }
+static inline float tk_sinf(float x) { return (float)sin((double)x); }
+static inline float tk_acosf(float x) { return (float)acos((double)x); }
+static inline float tk_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+/* src/core/sampling.cpp:60-77: float cos / sin, float products. */
 static void concentric_disk(float ux, float uy, float* dx, float* dy) {
     float ox = ux * 2.f - 1.0f, oy = uy * 2.f - 1.0f;
     if (ox == 0.0f && oy == 0.f) { *dx = ox; *dy = oy; return; }
@@ -207,8 +215,8 @@ static void concentric_disk(float ux, float uy, float* dx, float* dy) {
         r = oy;
         theta = (float)(k_half_pi - k_half_pi * 0.5 * (ox / oy));
     }
-    *dx = (float)(r * cos(theta));
-    *dy = (float)(r * sin(theta));
+    *dx = r * tk_cosf(theta);
+    *dy = r * tk_sinf(theta);
 }
 /* src/core/sampling.h:32-37 */
 static v3 cosine_hemisphere(float ux, float uy) {
@@ -1018,8 +1026,10 @@ typedef struct {
     int px, py, sample_idx, spp, xs, ys, dim, seed;   /* src/core/sampler.h:10-54 */
     uint32_t rng_seed, rng_pixel, rng_iter;
     int rng_cost;
+    int no_jitter;   /* StratifiedSampler(..., jitter = false): delta = 0.5 (src/core/sampler.cpp:51, :61-62) */
 } Sampler;
 static float sampler_jitter(Sampler* s, int slot) {
+    if (s->no_jitter) return 0.5f;
     if (s->rng_cost) g_mt_sink = mt_cost(s->rng_pixel + (uint32_t)slot);
     return orc_rng_u01(s->rng_seed, s->rng_pixel, s->rng_iter, (uint32_t)slot);
 }
@@ -1071,15 +1081,16 @@ void orc_direction_tables(float* ct, float* st, float* cp, float* sp) {
         cp[i] = (float)cos(2.0 * radians); sp[i] = (float)sin(2.0 * radians);
     }
 }
-/* src/tracer/TkSppmTracer.cpp:135-140: theta from acos(double), phi from the
- * float product 255*atan2 divided by the float 2*pi. */
+/* src/tracer/TkSppmTracer.cpp:135-140: float acos / atan2 and float products
+ * (wo.z, Math::inv_pi and Math::pi are floats, 255 converts to float). */
 void orc_encode_direction(const float wo[3], uint8_t* theta, uint8_t* phi) {
     ensure_consts();
-    double th = 255 * acos((double)wo[2]) * k_inv_pi;
+    const float inv_pi = (float)k_inv_pi, pi = (float)k_pi;
+    float th = 255 * tk_acosf(wo[2]) * inv_pi;
     int t = th != th ? 255 : (int)th;          /* int(NaN) is undefined in the reference; clamp */
     if (t > 255) t = 255;
     if (t < 0) t = 0;
-    int p = (int)(255 * atan2((double)wo[1], (double)wo[0]) / (2 * k_pi));
+    int p = (int)(255 * tk_atan2f(wo[1], wo[0]) / (2 * pi));
     if (p < 0) p += 255;
     if (p > 255) p = 255;
     *theta = (uint8_t)t; *phi = (uint8_t)p;
@@ -1356,12 +1367,14 @@ void orc_pixel_update(int64_t n, float* flux, float* photons, float* radius2, co
         pixel_update_one(flux + 3 * i, photons + i, radius2 + i, ld3(lindir + 3 * i), found[i], radius2_ret[i]);
 }
 
-/* src/tracer/TkSppmTracer.cpp:514-529 */
+/* src/tracer/TkSppmTracer.cpp:514-529.  The reference keeps the two light-path
+ * totals in s32 members (src/tracer/TkSppmTracer.h:31-32), which wrap on long
+ * jobs; here they are 64-bit and convert to float directly. */
 void orc_resolve_rgb8(const TkSPPMPixel* pp, int w, int h, int num_recurse, int64_t shoot_global,
                       int64_t shoot_caustic, int caustic_stored, uint8_t* out) {
     ensure_consts();
     size_t off = 0;
-    float sg = (float)(int32_t)shoot_global, sc = (float)(int32_t)shoot_caustic;
+    float sg = (float)shoot_global, sc = (float)shoot_caustic;
     for (int y = h; y-- > 0;) {
         for (int x = 0; x < w; ++x) {
             const TkSPPMPixel* p = &pp[x + y * w];
@@ -1390,7 +1403,7 @@ struct orc_sppm {
     int num_recurse, xs, ys, max_depth;
     float rr;
     uint32_t seed;
-    int rank, world, threads, split_mode, faithful, rng_cost;
+    int rank, world, threads, split_mode, faithful, rng_cost, no_jitter;
     orc_map* gmap; orc_map* cmap;
     int64_t quota_g, quota_c;
     /* this rank's traced photons (before exchange) */
@@ -1633,7 +1646,7 @@ static int camera_path(const orc_sppm* r, int iter, int x, int y, TkSPPMPixel* p
     Sampler sm;
     sm.px = x; sm.py = y; sm.sample_idx = iter; sm.spp = r->num_recurse; sm.xs = r->xs; sm.ys = r->ys;
     sm.dim = 0; sm.seed = 0;
-    sm.rng_seed = r->seed; sm.rng_pixel = (uint32_t)(x + y * s->w); sm.rng_iter = (uint32_t)iter; sm.rng_cost = r->rng_cost;
+    sm.rng_seed = r->seed; sm.rng_pixel = (uint32_t)(x + y * s->w); sm.rng_iter = (uint32_t)iter; sm.rng_cost = r->rng_cost; sm.no_jitter = r->no_jitter;
     float cx, cy, lx, ly;
     sampler_get2d(&sm, &cx, &cy);
     cx = cx + (float)x; cy = cy + (float)y;
@@ -1753,6 +1766,8 @@ orc_sppm* orc_sppm_begin(orc_scene* s, const TkSppmParam* param, int max_depth, 
     for (size_t i = 0; i < np; ++i) { r->pp[i].causticRadius2 = param->radius2; r->pp[i].globalRadius2 = param->radius2; }
     return r;
 }
+/* jitter = 0: the camera sampler is the reference's StratifiedSampler built with jitter = false. */
+void orc_sppm_set_jitter(orc_sppm* r, int jitter) { r->no_jitter = jitter ? 0 : 1; }
 void orc_sppm_destroy(orc_sppm* r) {
     if (!r) return;
     orc_map_destroy(r->gmap); orc_map_destroy(r->cmap);

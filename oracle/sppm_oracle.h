@@ -87,6 +87,8 @@ orc_sppm* orc_sppm_begin(orc_scene* s, const TkSppmParam* param, int max_depth, 
                          uint64_t seed, int rank, int world, int threads, int split_mode,
                          int faithful_bvh, int rng_cost);
 void orc_sppm_destroy(orc_sppm* r);
+/* jitter 0: stratum centres, as StratifiedSampler(x, y, jitter = false) (src/core/sampler.cpp:51, :61-62). */
+void orc_sppm_set_jitter(orc_sppm* r, int jitter);
 void orc_sppm_photon_pass(orc_sppm* r, int iter, TkIterStats* st);
 void orc_sppm_build_maps(orc_sppm* r, TkIterStats* st);
 /* y0,y1: restrict the camera pass to rows [y0,y1) (bounded CPU baseline sample);

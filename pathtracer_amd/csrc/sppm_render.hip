@@ -115,6 +115,7 @@ struct SppmState {
     int num_recurse = 1, xs = 1, ys = 1, max_depth = 20;
     float rr = 0.8f;
     uint32_t seed = 0;
+    int no_jitter = 0;               // tkhip_sppm_set_jitter
     int rank = 0, world = 1;
     tkhip_map* map[2] = {nullptr, nullptr};
     int64_t quota[2] = {0, 0};
@@ -419,6 +420,7 @@ struct CameraArgs {
     int64_t n_pixels;
     int iter, spp, xs, ys, depth;
     uint32_t seed;
+    int no_jitter;
     int caustic_stored;
     float4* gq;          // global queries: 4 arrays of capacity n_slots, back to back
     float4* cq;          // caustic queries
@@ -430,6 +432,7 @@ TKD Sampler make_sampler(const CameraArgs& a, int x, int y, int dim) {
     Sampler s;
     s.px = x; s.py = y; s.sample_idx = a.iter; s.spp = a.spp; s.xs = a.xs; s.ys = a.ys; s.dim = dim;
     s.rng_seed = a.seed; s.rng_pixel = (uint32_t)(x + y * a.cam.w); s.rng_iter = (uint32_t)a.iter;
+    s.no_jitter = a.no_jitter != 0;
     return s;
 }
 
@@ -904,6 +907,7 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.n_pixels = s->n_pixels;
     a.iter = iter; a.spp = s->num_recurse; a.xs = s->xs; a.ys = s->ys; a.depth = s->max_depth;
     a.seed = s->seed;
+    a.no_jitter = s->no_jitter;
     a.caustic_stored = expect_caustic ? 1 : 0;
     a.gq = s->qbuf[0].as<float4>();
     a.cq = s->qbuf[1].as<float4>();
@@ -1271,6 +1275,12 @@ int tkhip_sppm_set_tree(tkhip_ctx* ctx, int mode) {
     return tkhip_map_set_tree(ctx->sppm->map[1], mode);
 }
 
+int tkhip_sppm_set_jitter(tkhip_ctx* ctx, int jitter) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_set_jitter");
+    ctx->sppm->no_jitter = jitter ? 0 : 1;
+    return TKHIP_OK;
+}
+
 int tkhip_sppm_camera_begin(tkhip_ctx* ctx, int iter) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_camera_begin");
     SppmState* s = ctx->sppm;
@@ -1433,8 +1443,8 @@ int tkhip_sppm_resolve_rgb8(tkhip_ctx* ctx, int iterations, uint8_t* host_out) {
     SppmState* s = ctx->sppm;
     TK_TRY(ctx->scratch_a.ensure((size_t)s->n_pixels * 3));
     k_resolve<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, ctx->cam.w, ctx->cam.h,
-                                                               iterations, (float)(int32_t)s->shoot[0],
-                                                               (float)(int32_t)s->shoot[1], (int)s->stored_c,
+                                                               iterations, (float)s->shoot[0],
+                                                               (float)s->shoot[1], (int)s->stored_c,
                                                                ctx->scratch_a.as<uint8_t>());
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(host_out, ctx->scratch_a.p, (size_t)s->n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));

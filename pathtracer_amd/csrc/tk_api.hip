@@ -284,6 +284,43 @@ __global__ void k_sample_le(DScene sc, int li, int64_t n, const float* u1, const
     o[6] = e.n.x; o[7] = e.n.y; o[8] = e.n.z; o[9] = e.Le.x; o[10] = e.Le.y; o[11] = e.Le.z;
     o[12] = e.pdf_pos; o[13] = e.pdf_dir;
 }
+// StratifiedSampler::get1D / get2D (src/core/sampler.cpp:46-64) for n (pixel, sample) pairs, each
+// drawing the same sequence of 1-D and 2-D samples from dimension 0 on.
+__global__ void k_stratified(int64_t n, const int32_t* px, const int32_t* py, const int32_t* idx, const int32_t* xs,
+                             const int32_t* ys, int n_draws, const uint8_t* draws, int floats_per, int jitter, uint32_t seed,
+                             float* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Sampler s;
+    s.px = px[i]; s.py = py[i]; s.sample_idx = idx[i]; s.xs = xs[i]; s.ys = ys[i]; s.spp = xs[i] * ys[i]; s.dim = 0;
+    s.rng_seed = seed; s.rng_pixel = (uint32_t)(px[i] + py[i] * 65536); s.rng_iter = (uint32_t)idx[i];
+    s.no_jitter = jitter == 0;
+    float* o = out + i * floats_per;
+    for (int d = 0; d < n_draws; ++d) {
+        if (draws[d] == 1) *o++ = sampler_get1d(s);
+        else { sampler_get2d(s, o, o + 1); o += 2; }
+    }
+}
+// Intersection::spawnRay / spawnRayTo(pos) (src/Intersection.hpp:25-38, src/Ray.hpp:43-57):
+// in  = p, pError, n, w, target (5 x 3 floats); out = origin along w, origin towards target, direction to target.
+__global__ void k_spawn_ray(int64_t n, const float* in, float* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + 15 * i;
+    const F3 p = ld3(a), pe = ld3(a + 3), nn = ld3(a + 6), w = ld3(a + 9), tg = ld3(a + 12);
+    const F3 o1 = offset_ray_origin(p, pe, nn, w);
+    const F3 o2 = offset_ray_origin(p, pe, nn, sub3(tg, p));
+    const F3 d2 = sub3(tg, o2);
+    float* o = out + 9 * i;
+    o[0] = o1.x; o[1] = o1.y; o[2] = o1.z; o[3] = o2.x; o[4] = o2.y; o[5] = o2.z; o[6] = d2.x; o[7] = d2.y; o[8] = d2.z;
+}
+__global__ void k_encode_direction(int64_t n, const float* wo, uint8_t* theta, uint8_t* phi) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = encode_direction(ld3(wo + 3 * i));
+    theta[i] = (uint8_t)(b & 255u);
+    phi[i] = (uint8_t)(b >> 8);
+}
 }  // namespace tkd
 
 int tkhip_sample_f(tkhip_ctx* ctx, const TkMaterial* material, int mode, int64_t n, const float* wo, const float* nrm,
@@ -337,6 +374,88 @@ int tkhip_sample_le(tkhip_ctx* ctx, int light, int64_t n, const float* u1, const
         for (int a = 0; a < 3; ++a) { org[3 * i + a] = o[a]; dir[3 * i + a] = o[3 + a]; nrm[3 * i + a] = o[6 + a]; le[3 * i + a] = o[9 + a]; }
         pdf_pos[i] = o[12]; pdf_dir[i] = o[13];
     }
+    return TKHIP_OK;
+}
+
+int tkhip_stratified_samples(tkhip_ctx* ctx, int64_t n, const int32_t* px, const int32_t* py, const int32_t* sample_idx,
+                             const int32_t* xs, const int32_t* ys, int n_draws, const uint8_t* draws, int jitter,
+                             uint64_t seed, float* out) {
+    TK_REQUIRE(ctx && (n == 0 || (px && py && sample_idx && xs && ys && out)) && draws, TKHIP_E_ARG,
+               "tkhip_stratified_samples: null argument");
+    TK_REQUIRE(n >= 0 && n_draws >= 1 && n_draws <= 256, TKHIP_E_LIMIT, "tkhip_stratified_samples: 1..256 draws per sample");
+    int floats_per = 0;
+    for (int d = 0; d < n_draws; ++d) {
+        TK_REQUIRE(draws[d] == 1 || draws[d] == 2, TKHIP_E_ARG, "tkhip_stratified_samples: a draw is 1 (get1D) or 2 (get2D)");
+        floats_per += draws[d];
+    }
+    for (int64_t i = 0; i < n; ++i)
+        TK_REQUIRE(xs[i] >= 1 && ys[i] >= 1 && sample_idx[i] >= 0 && sample_idx[i] < xs[i] * ys[i], TKHIP_E_ARG,
+                   "tkhip_stratified_samples: sample %lld: index %d outside %d x %d strata", (long long)i, sample_idx[i], xs[i], ys[i]);
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t q = (size_t)n;
+    TK_TRY(ctx->scratch_a.ensure(q * 20 + 256));
+    TK_TRY(ctx->scratch_b.ensure(q * (size_t)floats_per * 4));
+    int32_t* d = ctx->scratch_a.as<int32_t>();
+    uint8_t* dd = reinterpret_cast<uint8_t*>(d + 5 * q);
+    const int32_t* host[5] = {px, py, sample_idx, xs, ys};
+    for (int a = 0; a < 5; ++a) TK_HIP(hipMemcpyAsync(d + a * q, host[a], q * 4, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(dd, draws, (size_t)n_draws, hipMemcpyHostToDevice, s));
+    k_stratified<<<divup(n, 256), 256, 0, s>>>(n, d, d + q, d + 2 * q, d + 3 * q, d + 4 * q, n_draws, dd, floats_per, jitter,
+                                               (uint32_t)seed, ctx->scratch_b.as<float>());
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(out, ctx->scratch_b.p, q * (size_t)floats_per * 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    return TKHIP_OK;
+}
+
+int tkhip_spawn_rays(tkhip_ctx* ctx, int64_t n, const float* p, const float* perr, const float* nrm, const float* w,
+                     const float* target, float* org, float* org_to, float* dir_to) {
+    TK_REQUIRE(ctx && (n == 0 || (p && perr && nrm && w && target && org && org_to && dir_to)), TKHIP_E_ARG,
+               "tkhip_spawn_rays: null argument");
+    TK_REQUIRE(n >= 0, TKHIP_E_ARG, "tkhip_spawn_rays: negative count");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t q = (size_t)n;
+    std::vector<float> in(q * 15), out(q * 9);
+    const float* src[5] = {p, perr, nrm, w, target};
+    for (size_t i = 0; i < q; ++i)
+        for (int a = 0; a < 5; ++a)
+            for (int c = 0; c < 3; ++c) in[i * 15 + (size_t)a * 3 + c] = src[a][i * 3 + c];
+    TK_TRY(ctx->scratch_a.ensure(q * 60));
+    TK_TRY(ctx->scratch_b.ensure(q * 36));
+    TK_HIP(hipMemcpyAsync(ctx->scratch_a.p, in.data(), q * 60, hipMemcpyHostToDevice, s));
+    k_spawn_ray<<<divup(n, 256), 256, 0, s>>>(n, ctx->scratch_a.as<float>(), ctx->scratch_b.as<float>());
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(out.data(), ctx->scratch_b.p, q * 36, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < q; ++i)
+        for (int c = 0; c < 3; ++c) {
+            org[i * 3 + c] = out[i * 9 + c];
+            org_to[i * 3 + c] = out[i * 9 + 3 + c];
+            dir_to[i * 3 + c] = out[i * 9 + 6 + c];
+        }
+    return TKHIP_OK;
+}
+
+int tkhip_encode_directions(tkhip_ctx* ctx, int64_t n, const float* wo, uint8_t* theta, uint8_t* phi) {
+    TK_REQUIRE(ctx && (n == 0 || (wo && theta && phi)), TKHIP_E_ARG, "tkhip_encode_directions: null argument");
+    TK_REQUIRE(n >= 0, TKHIP_E_ARG, "tkhip_encode_directions: negative count");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t q = (size_t)n;
+    TK_TRY(ctx->scratch_a.ensure(q * 12));
+    TK_TRY(ctx->scratch_b.ensure(q * 2));
+    uint8_t* d = ctx->scratch_b.as<uint8_t>();
+    TK_HIP(hipMemcpyAsync(ctx->scratch_a.p, wo, q * 12, hipMemcpyHostToDevice, s));
+    k_encode_direction<<<divup(n, 256), 256, 0, s>>>(n, ctx->scratch_a.as<float>(), d, d + q);
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(theta, d, q, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipMemcpyAsync(phi, d + q, q, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
     return TKHIP_OK;
 }
 

@@ -145,8 +145,8 @@ TKD bool tri_hit(const TriIsect& T, F3 o, F3 d, double tmax, double* tout, doubl
 }
 
 // Slab test with the tMax padding of src/Bounds3.hpp:108-118; returns the
-// entry distance.  fminf/fmaxf drop NaNs from 0*inf, which only ever widens
-// the interval.
+// entry distance.  For a direction without zero components (finite inverses)
+// this min / max form decides exactly as the CPU code does.
 TKD bool box_hit(const float* bmin, const float* bmax, F3 o, F3 dinv, float tmax, float* tnear) {
     const float pad = 1 + 2 * gamma_n(3);
     float tx0 = (bmin[0] - o.x) * dinv.x, tx1 = (bmax[0] - o.x) * dinv.x;
@@ -156,6 +156,33 @@ TKD bool box_hit(const float* bmin, const float* bmax, F3 o, F3 dinv, float tmax
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * pad;
     *tnear = tn;
     return tn <= tf && tf > 0 && tn < tmax;
+}
+// The same test for a ray with an infinite inverse (a zero direction component),
+// statement by statement as Bounds3::IntersectP makes it (src/Bounds3.hpp:96-125):
+// the slab bound is picked by `dir > 0`, so a +0 component takes the far plane
+// as entry (+inf: the ray misses every box), a -0 component passes, and a NaN
+// from 0 * inf goes through the comparisons as it does there.
+TKD bool box_hit_zero_dir(const float* bmin, const float* bmax, F3 o, F3 d, F3 dinv, float tmax, float* tnear) {
+    const float pad = 1 + 2 * gamma_n(3);
+    const bool px = d.x > 0, py = d.y > 0, pz = d.z > 0;
+    float tMin = ((px ? bmin[0] : bmax[0]) - o.x) * dinv.x;
+    float tMax = ((px ? bmax[0] : bmin[0]) - o.x) * dinv.x;
+    float tyMin = ((py ? bmin[1] : bmax[1]) - o.y) * dinv.y;
+    float tyMax = ((py ? bmax[1] : bmin[1]) - o.y) * dinv.y;
+    tMax *= pad;
+    tyMax *= pad;
+    *tnear = 0.f;
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((pz ? bmin[2] : bmax[2]) - o.z) * dinv.z;
+    float tzMax = ((pz ? bmax[2] : bmin[2]) - o.z) * dinv.z;
+    tzMax *= pad;
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    *tnear = tMin;
+    return (tMin <= tMax) && (tMax > 0) && !(tMin >= tmax);
 }
 
 TKD void prim_test(const DScene& sc, const TriIsect& T, F3 o, F3 d, Hit* h) {
@@ -209,6 +236,7 @@ struct RayWalk {
     int sp;
     float tcull;
     F3 dinv;
+    bool zero_dir;  // some component of the direction has an infinite inverse: the slow exact slab test
     Hit h;
 };
 TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
@@ -217,6 +245,7 @@ TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
     // fp32 quotient is the same number: 1/x for a 24-bit x never lies within a double's rounding
     // error of a midpoint between two floats.
     w.dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.zero_dir = isinf(w.dinv.x) || isinf(w.dinv.y) || isinf(w.dinv.z);
     w.tcull = tmax >= 3.0e38 ? 3.4e38f : (float)tmax * 1.0000002f;
     w.sp = 0;
     w.cur = sc.n_nodes == 0 ? kWalkOver : 0;
@@ -235,8 +264,14 @@ TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK
             if (!inner) continue;
             const BvhNode nd = sc.nodes[w.cur];
             float tl, tr;
-            const bool hl = box_hit(nd.lmin, nd.lmax, o, w.dinv, w.tcull, &tl);
-            const bool hr = box_hit(nd.rmin, nd.rmax, o, w.dinv, w.tcull, &tr);
+            bool hl, hr;
+            if (__builtin_expect(w.zero_dir, 0)) {
+                hl = box_hit_zero_dir(nd.lmin, nd.lmax, o, d, w.dinv, w.tcull, &tl);
+                hr = box_hit_zero_dir(nd.rmin, nd.rmax, o, d, w.dinv, w.tcull, &tr);
+            } else {
+                hl = box_hit(nd.lmin, nd.lmax, o, w.dinv, w.tcull, &tl);
+                hr = box_hit(nd.rmin, nd.rmax, o, w.dinv, w.tcull, &tr);
+            }
             if (hl && hr) {
                 const bool right_first = tr < tl;
                 st.push(w.sp, right_first ? nd.left : nd.right);

@@ -180,13 +180,17 @@ TKD int permutation_element(uint32_t i, uint32_t l, uint32_t p) {   // src/TkMat
 struct Sampler {
     int px, py, sample_idx, spp, xs, ys, dim;
     uint32_t rng_seed, rng_pixel, rng_iter;
+    bool no_jitter;   // StratifiedSampler(..., jitter = false): stratum centres (src/core/sampler.cpp:51, :61-62)
 };
+TKD float sampler_jitter(const Sampler& s, int slot) {
+    return s.no_jitter ? 0.5f : rng_u01(s.rng_seed, s.rng_pixel, s.rng_iter, (uint32_t)slot);
+}
 TKD float sampler_get1d(Sampler& s) {
     uint64_t hash = hash_pixel(s.px, s.py, s.dim, 0);
     int stratum = permutation_element((uint32_t)s.sample_idx, (uint32_t)s.spp, (uint32_t)hash);
     int d = s.dim;
     ++s.dim;
-    float delta = rng_u01(s.rng_seed, s.rng_pixel, s.rng_iter, (uint32_t)(2 * d));
+    float delta = sampler_jitter(s, 2 * d);
     return (stratum + delta) / s.spp;
 }
 TKD void sampler_get2d(Sampler& s, float* ox, float* oy) {
@@ -197,13 +201,22 @@ TKD void sampler_get2d(Sampler& s, float* ox, float* oy) {
     int x, y;
     if ((s.xs & (s.xs - 1)) == 0) { x = stratum & (s.xs - 1); y = stratum >> (__ffs(s.xs) - 1); }   // no division for 2^n strata
     else { x = stratum % s.xs; y = stratum / s.xs; }
-    float dx = rng_u01(s.rng_seed, s.rng_pixel, s.rng_iter, (uint32_t)(2 * d));
-    float dy = rng_u01(s.rng_seed, s.rng_pixel, s.rng_iter, (uint32_t)(2 * d + 1));
+    float dx = sampler_jitter(s, 2 * d);
+    float dy = sampler_jitter(s, 2 * d + 1);
     *ox = (x + dx) / s.xs;
     *oy = (y + dy) / s.ys;
 }
 
 // ------------------------------------------------------------- sampling
+// Correctly rounded float sine / cosine / arc functions: the double function,
+// rounded to float.  The CPU code's unqualified cos / sin / acos / atan2 on
+// float arguments are the float overloads of the host's libm, whose last bit
+// differs from platform to platform; this form gives the same value on the
+// host and on the GPU.
+TKD float tk_cosf(float x) { return (float)cos((double)x); }
+TKD float tk_sinf(float x) { return (float)sin((double)x); }
+TKD float tk_acosf(float x) { return (float)acos((double)x); }
+TKD float tk_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
 TKD void concentric_disk(float ux, float uy, float* dx, float* dy) {   // src/core/sampling.cpp:60-77
     float ox = ux * 2.f - 1.0f, oy = uy * 2.f - 1.0f;
     if (ox == 0.0f && oy == 0.f) { *dx = ox; *dy = oy; return; }
@@ -215,10 +228,8 @@ TKD void concentric_disk(float ux, float uy, float* dx, float* dy) {   // src/co
         r = oy;
         theta = (float)((double)kHalfPi - (double)kHalfPi * 0.5 * (double)(ox / oy));
     }
-    float s, c;
-    sincosf(theta, &s, &c);
-    *dx = r * c;
-    *dy = r * s;
+    *dx = r * tk_cosf(theta);
+    *dy = r * tk_sinf(theta);
 }
 TKD F3 cosine_hemisphere(float ux, float uy) {                 // src/core/sampling.h:32-37
     float dx, dy;
@@ -304,14 +315,14 @@ TKD F3 offset_ray_origin(F3 p, F3 perr, F3 n, F3 w) {          // src/Ray.hpp:43
     return po;
 }
 
-// Photon direction quantisation (src/tracer/TkSppmTracer.cpp:135-140): theta
-// from the double acos, phi from the float quotient; acos of a value just above
-// one gives NaN, which the CPU code converts with undefined behaviour: clamp.
+// Photon direction quantisation (src/tracer/TkSppmTracer.cpp:135-140): float
+// acos / atan2 and float products; acos of a value just above one gives NaN,
+// which the CPU code converts with undefined behaviour: clamp.
 TKD uint32_t encode_direction(F3 wo) {
-    double th = 255 * acos((double)wo.z) * (double)kInvPi;
+    float th = 255 * tk_acosf(wo.z) * kInvPi;
     int t = (th != th) ? 255 : (int)th;
     t = t > 255 ? 255 : (t < 0 ? 0 : t);
-    int p = (int)(255 * atan2((double)wo.y, (double)wo.x) / (double)(2 * kPi));
+    int p = (int)(255 * tk_atan2f(wo.y, wo.x) / (2 * kPi));
     if (p < 0) p += 255;
     if (p > 255) p = 255;
     return (uint32_t)t | ((uint32_t)p << 8);

@@ -117,6 +117,32 @@ class Context:
               "tkhip_radical_inverse")
         return out
 
+    def stratified_samples(self, px, py, sample_idx, xs, ys, draws, jitter=False, seed=0):
+        """StratifiedSampler draws (1 = get1D, 2 = get2D) for n (pixel, sample index) pairs."""
+        arrs = [np.ascontiguousarray(a, np.int32) for a in (px, py, sample_idx, xs, ys)]
+        draws = np.ascontiguousarray(draws, np.uint8)
+        n = arrs[0].shape[0]
+        out = np.empty((n, int(draws.sum())), np.float32)
+        check(self.lib, self.lib.tkhip_stratified_samples(self.h, n, *[_ip(a) for a in arrs], draws.shape[0], _bp(draws),
+                                                          1 if jitter else 0, seed, _fp(out)), "tkhip_stratified_samples")
+        return out
+
+    def spawn_rays(self, p, perr, nrm, w, target):
+        """Intersection::spawnRay(w) origin, spawnRayTo(target) origin and direction."""
+        ins = [_f32(a) for a in (p, perr, nrm, w, target)]
+        n = ins[0].shape[0]
+        outs = [np.empty((n, 3), np.float32) for _ in range(3)]
+        check(self.lib, self.lib.tkhip_spawn_rays(self.h, n, *[_fp(a) for a in ins], *[_fp(o) for o in outs]),
+              "tkhip_spawn_rays")
+        return tuple(outs)
+
+    def encode_directions(self, wo):
+        wo = _f32(wo)
+        n = wo.shape[0]
+        th, ph = np.empty(n, np.uint8), np.empty(n, np.uint8)
+        check(self.lib, self.lib.tkhip_encode_directions(self.h, n, _fp(wo), _bp(th), _bp(ph)), "tkhip_encode_directions")
+        return th, ph
+
     def pixel_update(self, flux, photons, radius2, lindir, found, radius2_ret):
         flux, photons, radius2 = _f32(flux).copy(), _f32(photons).copy(), _f32(radius2).copy()
         lindir, radius2_ret = _f32(lindir), _f32(radius2_ret)
@@ -236,6 +262,10 @@ class SppmTracer:
         self.cur_recurse = 0
         self.stats = []
         self.state = "RENDERING"
+
+    def set_jitter(self, on):
+        """False: the camera sampler takes stratum centres (StratifiedSampler with jitter = false)."""
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_set_jitter(self.ctx.h, 1 if on else 0), "tkhip_sppm_set_jitter")
 
     # phases of one iteration (world > 1 drives them separately around the exchange)
     def photon_pass(self, it, stats=None):

@@ -1,0 +1,176 @@
+"""The HIP kernels against outputs of the upstream renderer itself
+(tests/golden/ref_*.npz, see tests/test_ref_pinned_cpu.py and
+oracle/make_ref_golden.py).  Every call goes through the C ABI of libtkhip.so.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd.scene import Scene, asset_scene
+from pathtracer_amd.tracer import PhotonMap, SppmTracer
+from tests.conftest import golden
+from tests.ref_fixtures import (MATERIALS, TILE_DRAWS, assert_pixels_match, bits_equal, light_pick_candidates,
+                                object_of_prim, tk_material)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_radical_inverse_matches_upstream(gpu_ctx):
+    g = golden("ref_lowdiscrepancy.npz")
+    assert bits_equal(gpu_ctx.radical_inverse(g["radinv_dim"], g["radinv_index"]), g["radinv_value"])
+
+
+def test_stratified_sampler_matches_upstream(gpu_ctx):
+    """Hash, PermutationElement and the stratum arithmetic of get1D / get2D, jitter off."""
+    g = golden("ref_lowdiscrepancy.npz")
+    out = gpu_ctx.stratified_samples(g["strat_x"], g["strat_y"], g["strat_idx"], g["strat_xs"], g["strat_ys"], TILE_DRAWS,
+                                     jitter=False)
+    assert bits_equal(out, g["strat_values"])
+    # with jitter every draw stays inside its stratum
+    jit = gpu_ctx.stratified_samples(g["strat_x"], g["strat_y"], g["strat_idx"], g["strat_xs"], g["strat_ys"], TILE_DRAWS,
+                                     jitter=True, seed=7)
+    col = 0
+    for d in TILE_DRAWS:
+        for a in range(d):
+            n = (g["strat_xs"] * g["strat_ys"]) if d == 1 else (g["strat_xs"] if a == 0 else g["strat_ys"])
+            assert (np.floor(jit[:, col] * n) == np.floor(out[:, col] * n)).all()
+            col += 1
+    assert not bits_equal(jit, out)
+
+
+@pytest.mark.parametrize("tag", ["knn100", "knn50"])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("tree", [0, 1])
+def test_knn_sets_match_upstream(gpu_ctx, tag, mode, tree):
+    """neighbor_search + radiance_estimate on upstream's own photon map object: found, returned
+    radius and neighbour index sets bit-exact, flux within 1e-5 relative."""
+    g = golden("ref_knn.npz")
+    k, n = int(g[tag + "_k"][0]), len(g[tag + "_theta"])
+    m = PhotonMap(gpu_ctx, n, k)
+    m.store(g[tag + "_pos"], g[tag + "_power"], g[tag + "_theta"], g[tag + "_phi"])
+    m.set_tree(tree)
+    m.build()
+    fl, fo, r2, idx = m.gather(g[tag + "_q_p"], g[tag + "_q_n"], g[tag + "_q_wo"], g[tag + "_q_R"], g[tag + "_q_radius2"],
+                               mode=mode)
+    m.close()
+    assert (fo == g[tag + "_found"]).all()
+    assert bits_equal(r2, g[tag + "_radius2_out"])
+    assert (idx == g[tag + "_idx"]).all()
+    np.testing.assert_allclose(fl, g[tag + "_flux"], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_knn_ties_match_upstream_up_to_the_tie(gpu_ctx, mode):
+    """Ties at the k-th distance: the lower index wins here, upstream keeps what its traversal met
+    first; count, radius, the distances of the set and the estimate agree."""
+    g = golden("ref_knn.npz")
+    tag, k, n = "knnties", int(g["knnties_k"][0]), len(g["knnties_theta"])
+    m = PhotonMap(gpu_ctx, n, k)
+    m.store(g[tag + "_pos"], g[tag + "_power"], g[tag + "_theta"], g[tag + "_phi"])
+    m.build()
+    q = g[tag + "_q_p"]
+    fl, fo, r2, idx = m.gather(q, g[tag + "_q_n"], g[tag + "_q_wo"], g[tag + "_q_R"], g[tag + "_q_radius2"], mode=mode)
+    m.close()
+    assert (fo == g[tag + "_found"]).all()
+    assert bits_equal(r2, g[tag + "_radius2_out"])
+    np.testing.assert_allclose(fl, g[tag + "_flux"], rtol=1e-5)
+    pos = g[tag + "_pos"]
+    for i in range(len(q)):
+        sel = idx[i][idx[i] >= 0]
+        d = pos[sel] - q[i]
+        d2 = np.sort((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32))
+        assert bits_equal(d2, g[tag + "_dist2"][i][: len(d2)]), i
+
+
+@pytest.mark.parametrize("name", ["box", "sphere", "dragon"])
+def test_ray_hits_match_upstream(gpu_ctx, name):
+    """Scene::intersect of upstream (its loader, its BVHs, its triangle and sphere tests) against the
+    flattened BVH walk: hit / miss, t, p, n, pError bit for bit, and the object hit; then the spawned
+    ray origins on those hits (offsetRayOrigin) and the light's emission samples."""
+    g = golden(f"ref_rays_{name}.npz")
+    T = f"rays_{name}_"
+    sc = Scene.load(asset_scene(f"cornell_{name}.scene"))
+    gpu_ctx.set_scene(sc)
+    prim, t, p, nrm, perr = gpu_ctx.trace_rays(g[T + "org"], g[T + "dir"])
+    hit = g[T + "hit"] == 1
+    assert ((prim >= 0) == hit).all()
+    assert bits_equal(t[hit], g[T + "t"][hit])
+    for mine, key in ((p, "p"), (nrm, "n"), (perr, "perr")):
+        assert bits_equal(mine[hit], g[T + key][hit]), key
+    assert (object_of_prim(sc, prim) == g[T + "obj"]).all()
+
+    a, out = g[T + "spawn_in"], g[T + "spawn_out"]
+    o1, o2, d2 = gpu_ctx.spawn_rays(*(a[:, i] for i in range(5)))
+    assert bits_equal(o1, out[:, 0]) and bits_equal(o2, out[:, 1]) and bits_equal(d2, out[:, 2])
+
+    # AreaLight::sample_Le: upstream picks the light's triangle with an unseeded random number, so
+    # each output must equal ours for one of the picks.  The direction comes from cosf / sinf of the
+    # disk mapping (last bit platform dependent, amplified near grazing by z = sqrt(1 - x^2 - y^2)).
+    L = T + "le_"
+    n = len(g[L + "u1"])
+    matched = np.zeros(n, bool)
+    for upick in light_pick_candidates(sc, 0):
+        org, d, nl, le, pp, pd = gpu_ctx.sample_le(0, g[L + "u1"], g[L + "u2"], np.full(n, upick, np.float32))
+        matched |= (bits_equal(org, g[L + "org"], per_row=True) & bits_equal(nl, g[L + "n"], per_row=True) &
+                    bits_equal(le, g[L + "L"], per_row=True) & (pp == g[L + "pdf"][:, 0]) &
+                    (np.abs(d - g[L + "dir"]).max(1) < 1e-6) & (np.abs(pd - g[L + "pdf"][:, 1]) <= 2e-5 * np.abs(pd) + 1e-7))
+    assert matched.all(), int((~matched).sum())
+
+
+@pytest.mark.parametrize("tag", list(MATERIALS))
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sample_f_matches_upstream(gpu_ctx, tag, mode):
+    g = golden("ref_materials.npz")
+    wi, f, pdf = gpu_ctx.sample_f(tk_material(tag), mode, g["mat_wo"], g["mat_n"], g["mat_u"])
+    t = f"mat_{tag}_{'radiance' if mode == 0 else 'importance'}"
+    if tag == "diffuse":   # cosf / sinf of the disk mapping: the last bit belongs to the platform's libm
+        assert np.abs(wi - g[t + "_wi"]).max() < 3e-7
+        assert bits_equal(wi, g[t + "_wi"], per_row=True).mean() > 0.97
+        np.testing.assert_allclose(pdf, g[t + "_pdf"], rtol=2e-6, atol=1e-7)
+    else:
+        assert bits_equal(wi, g[t + "_wi"]) and bits_equal(pdf, g[t + "_pdf"])
+    assert bits_equal(f, g[t + "_f"])
+
+
+@pytest.mark.parametrize("W", [512, 784, 1024])
+def test_camera_rays_match_upstream(gpu_ctx, W):
+    g = golden("ref_camera.npz")
+    sc = Scene.load(asset_scene("cornell_sphere.scene"))
+    gpu_ctx.set_camera(sc, W, W)
+    o, d = gpu_ctx.camera_rays(g[f"camera{W}_raster"])
+    assert bits_equal(o, g[f"camera{W}_org"]) and bits_equal(d, g[f"camera{W}_dir"])
+
+
+@pytest.mark.parametrize("tree", [0, 1])
+def test_trace_tile_matches_upstream(tree):
+    """SppmTracer::traceTile of upstream on given photon maps with an unjittered sampler, two
+    iterations, against tkhip_sppm_camera_pass on the same maps: camera paths, next-event estimation,
+    both radiance estimates and the SPPMPixel update.  Ld, photon counts and radii bit for bit,
+    fluxes within 1e-5 relative (order of the sum over the k photons)."""
+    import torch
+    g = golden("ref_trace_tile.npz")
+    W, H, kg, kc, rec, ng, nc = [int(v) for v in g["tile_meta"]]
+    sc = Scene.load(asset_scene("cornell_sphere.scene"))
+    tr = SppmTracer.from_scene(sc, globalSize=ng, causticSize=nc, numRecurse=rec, globalSample=kg, causticSample=kc)
+    tr.setScene(sc)
+    tr.setCamera(W, H)
+    tr.startRaytracing()
+    assert tr.num_recurse == int(g["tile_num_recurse"][0])
+    tr.set_jitter(False)
+    lib, h = tr.ctx.lib, tr.ctx.h
+    from pathtracer_amd._abi import check
+    check(lib, lib.tkhip_sppm_set_tree(h, tree), "tkhip_sppm_set_tree")
+    keep = []
+    for which, t in ((0, "g"), (1, "c")):
+        pos = torch.from_numpy(g[f"tile_{t}_pos"].copy()).cuda()
+        power = torch.from_numpy(g[f"tile_{t}_power"].copy()).cuda()
+        d = (g[f"tile_{t}_theta"].astype(np.int32) | (g[f"tile_{t}_phi"].astype(np.int32) << 8)).astype(np.int16)
+        dirs = torch.from_numpy(d).cuda()
+        keep += [pos, power, dirs]
+        torch.cuda.synchronize()
+        check(lib, lib.tkhip_sppm_set_map_photons(h, which, pos.data_ptr(), power.data_ptr(), dirs.data_ptr(), len(d), 0),
+              "tkhip_sppm_set_map_photons")
+    tr.build_maps()
+    for it in range(2):
+        tr.camera_pass(it)
+        assert_pixels_match(tr.pixels(), g[f"tile_pixels_iter{it}"])
+    tr.close()
