@@ -339,6 +339,24 @@ int tkhip_map_gather(tkhip_map* map, int64_t nq, const float* p, const float* n,
                      const float* R, const float* radius2, float* flux, int32_t* found,
                      float* radius2_out, int32_t* idx, int mode);
 
+/* tkhip_map_gather (production path, mode 0) for callers that cannot allocate
+ * device memory: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Every array is a
+ * DEVICE pointer (same shapes as tkhip_map_gather; idx may be null); the query
+ * order, the hand-over list between the two gather kernels and the sort's
+ * temporary storage live in one static device array of
+ * TKHIP_STATIC_SCRATCH_BYTES that the library holds on every GPU it runs on, so
+ * the call allocates and frees nothing.  At most TKHIP_STATIC_MAX_QUERIES
+ * queries per call (TKHIP_E_LIMIT beyond).  All calls on one GPU share that
+ * array: calls that overlap on one GPU race and must be serialised by the
+ * caller.  Work is enqueued on the map's stream; the call returns after it has
+ * finished. */
+#define TKHIP_STATIC_MAX_QUERIES 65536
+#define TKHIP_STATIC_SCRATCH_BYTES (8 << 20)
+int tkhip_map_gather_static(tkhip_map* map, int64_t nq, const float* p, const float* n, const float* wo,
+                            const float* R, const float* radius2, float* flux, int32_t* found,
+                            float* radius2_out, int32_t* idx);
+
 /* Scene::intersect for n rays (src/core/Scene.cpp:22-25 -> src/BVH.cpp:245-288,
  * src/Triangle.cpp:15-52, src/Sphere.cpp:14-55).  Host arrays:
  *   in : org float[3n], dir float[3n], tmax float[n]

@@ -120,6 +120,8 @@ TKHIP_SYMBOLS = {
     "tkhip_map_tree_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "tkhip_map_gather": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_float_p, c_float_p, c_int32_p, c_float_p, c_int32_p, C.c_int]),
+    "tkhip_map_gather_static": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tkhip_trace_rays": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_int32_p,
                                    c_float_p, c_float_p, c_float_p, c_float_p]),
     "tkhip_pixel_update": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p,

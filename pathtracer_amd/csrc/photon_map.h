@@ -29,6 +29,16 @@ struct GatherOut {
     unsigned long long* overflow_sum; // optional: queries handed to the per-query kernel
 };
 
+// Device scratch of one gather of up to nq queries: sort keys and values of the query order, the
+// hand-over list between the two kernels, and the sort's temporary storage.
+struct GatherScratch {
+    uint32_t *q_keys_a, *q_keys_b, *q_vals_a, *q_order;
+    int32_t *overflow, *overflow_group, *group_leaves, *group_leaf_count;
+    int32_t* counter;            // 1 int, cleared per gather
+    void* sort_temp;
+    size_t sort_temp_bytes;
+};
+
 struct MapView {
     const float4* pos4;      // leaf order: x, y, z, original index (int bits)
     const float4* pow4;      // leaf order: r, g, b, theta | phi << 8 (int bits)
@@ -83,5 +93,8 @@ int map_reserve_build(tkhip_map* m);
 // Adds the pending event pair to the running totals (waits for the launch it brackets).
 int map_flush_timing(tkhip_map* m);
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed);
+// The same with the scratch given by the caller (nothing is allocated).
+int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed,
+                  const GatherScratch& sc);
 
 }  // namespace tkd

@@ -22,6 +22,7 @@
 #include "photon_map.h"
 
 #include <algorithm>
+#include <mutex>
 
 #include "tk_device.h"
 
@@ -993,6 +994,24 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
     if (nq == 0) return TKHIP_OK;
     TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
+    GatherScratch sc{};
+    if (mode == 0) {
+        TK_TRY(map_reserve_queries(m, nq));
+        sc.q_keys_a = m->q_keys_a.as<uint32_t>(); sc.q_keys_b = m->q_keys_b.as<uint32_t>();
+        sc.q_vals_a = m->q_vals_a.as<uint32_t>(); sc.q_order = m->q_order.as<uint32_t>();
+        sc.overflow = m->overflow.as<int32_t>(); sc.overflow_group = m->overflow_group.as<int32_t>();
+        sc.group_leaves = m->group_leaves.as<int32_t>(); sc.group_leaf_count = m->group_leaf_count.as<int32_t>();
+        sc.counter = m->counters.as<int32_t>();
+        sc.sort_temp = m->prim_temp.p; sc.sort_temp_bytes = m->prim_temp.bytes;
+    }
+    return map_gather_in(m, nq, qv, out, mode, timed, sc);
+}
+
+int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed,
+                  const GatherScratch& sc) {
+    TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
+    if (nq == 0) return TKHIP_OK;
+    TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
     hipStream_t s = m->stream;
     const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
     auto wave_all = [&](const int32_t* list, const int32_t* cnt, int64_t hint, const GroupLeaves& gl) {
@@ -1007,26 +1026,21 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         TK_LAUNCH_CHECK();
         return TKHIP_OK;
     }
-    TK_TRY(map_reserve_queries(m, nq));
     // Hilbert order inside the root box of the tree (heap node 1)
-    k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, m->q_keys_a.as<uint32_t>(),
-                                                 m->q_vals_a.as<uint32_t>());
+    k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, sc.q_keys_a, sc.q_vals_a);
     TK_LAUNCH_CHECK();
-    TK_TRY(sort_pairs_u32(s, m->prim_temp, m->q_keys_a.as<uint32_t>(), m->q_keys_b.as<uint32_t>(), m->q_vals_a.as<uint32_t>(),
-                          m->q_order.as<uint32_t>(), (size_t)nq, 30));
-    int32_t* ocount = m->counters.as<int32_t>();
+    TK_TRY(sort_pairs_u32_in(s, sc.sort_temp, sc.sort_temp_bytes, sc.q_keys_a, sc.q_keys_b, sc.q_vals_a, sc.q_order, (size_t)nq, 30));
+    int32_t* ocount = sc.counter;
     TK_HIP(hipMemsetAsync(ocount, 0, 4, s));
     TK_TRY(map_flush_timing(m));
     TK_HIP(hipEventRecord(m->ev_begin, s));
     const int64_t groups = (nq + 63) / 64;
-    const GroupLeaves gl{m->overflow_group.as<int32_t>(), m->group_leaves.as<int32_t>(), m->group_leaf_count.as<int32_t>()};
+    const GroupLeaves gl{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), 256 * 32);
     if (out.idx)
-        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
-                                                    m->overflow.as<int32_t>(), ocount, gl);
+        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, sc.q_order, nq, out, sc.overflow, ocount, gl);
     else
-        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, m->q_order.as<uint32_t>(), nq, out,
-                                                     m->overflow.as<int32_t>(), ocount, gl);
+        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, sc.q_order, nq, out, sc.overflow, ocount, gl);
     TK_LAUNCH_CHECK();
     TK_HIP(hipEventRecord(m->ev_end, s));
     m->ev_pending = true;
@@ -1035,7 +1049,7 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         TK_HIP(hipEventSynchronize(m->ev_end));
         TK_HIP(hipEventElapsedTime(&m->last_group_ms, m->ev_begin, m->ev_end));
     }
-    wave_all(m->overflow.as<int32_t>(), ocount, nq, gl);
+    wave_all(sc.overflow, ocount, nq, gl);
     TK_LAUNCH_CHECK();
     if (timed) {
         int32_t oc = 0;
@@ -1073,6 +1087,30 @@ __global__ void k_pixel_update(int64_t n, float* flux, float* photons, float* ra
                  found[i], r2ret[i]);
 }
 
+}  // namespace tkd
+
+
+// ------------------------------------------------- gather without allocation
+// Scratch of tkhip_map_gather_static: one array per GPU, part of the library's
+// code object (each GPU the library runs on holds its copy until the process
+// ends).  Host code never uses the array's name as an address: the address on a
+// device is looked up once (static_scratch_init, called by tkhip_create with
+// that device current) and kept per device.
+static __device__ __align__(256) unsigned char g_static_scratch[TKHIP_STATIC_SCRATCH_BYTES];
+static std::mutex g_static_mutex;
+static unsigned char* g_static_ptr[64] = {nullptr};
+
+namespace tkd {
+int static_scratch_init(int device) {
+    TK_REQUIRE(device >= 0 && device < 64, TKHIP_E_LIMIT, "static scratch: device %d outside 0..63", device);
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (g_static_ptr[device]) return TKHIP_OK;
+    void* ptr = nullptr;
+    TK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch)));
+    TK_REQUIRE(ptr != nullptr, TKHIP_E_HIP, "static scratch: no device address on device %d", device);
+    g_static_ptr[device] = static_cast<unsigned char*>(ptr);
+    return TKHIP_OK;
+}
 }  // namespace tkd
 
 // ------------------------------------------------------------------ C ABI
@@ -1194,6 +1232,57 @@ int tkhip_map_gather(tkhip_map* m, int64_t nq, const float* p, const float* n, c
     (void)hipStreamSynchronize(s);
     cleanup();
     return rc;
+}
+
+int tkhip_map_gather_static(tkhip_map* m, int64_t nq, const float* p, const float* n, const float* wo, const float* R,
+                            const float* radius2, float* flux, int32_t* found, float* radius2_out, int32_t* idx) {
+    TK_REQUIRE(m && (nq == 0 || (p && n && wo && R && radius2 && flux && found && radius2_out)), TKHIP_E_ARG,
+               "tkhip_map_gather_static: null argument");
+    TK_REQUIRE(m->built, TKHIP_E_STATE, "tkhip_map_gather_static: call tkhip_map_build first");
+    TK_REQUIRE(nq >= 0 && nq <= TKHIP_STATIC_MAX_QUERIES, TKHIP_E_LIMIT,
+               "tkhip_map_gather_static: %lld queries, the static scratch holds at most %d", (long long)nq,
+               TKHIP_STATIC_MAX_QUERIES);
+    if (nq == 0) return TKHIP_OK;
+    tkhip_ctx* ctx = m->ctx;
+    TK_HIP(hipSetDevice(ctx->device));
+    unsigned char* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_static_mutex);
+        base = ctx->device >= 0 && ctx->device < 64 ? g_static_ptr[ctx->device] : nullptr;
+    }
+    TK_REQUIRE(base != nullptr, TKHIP_E_STATE, "tkhip_map_gather_static: no static scratch on device %d", ctx->device);
+    // carve the array: everything sized for the maximum, so the layout does not depend on nq
+    const size_t Q = (size_t)TKHIP_STATIC_MAX_QUERIES;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { unsigned char* r = base + at; at += (bytes + 255) & ~(size_t)255; return r; };
+    float4* q4 = reinterpret_cast<float4*>(take(Q * 64));
+    GatherScratch sc{};
+    sc.q_keys_a = reinterpret_cast<uint32_t*>(take(Q * 4));
+    sc.q_keys_b = reinterpret_cast<uint32_t*>(take(Q * 4));
+    sc.q_vals_a = reinterpret_cast<uint32_t*>(take(Q * 4));
+    sc.q_order = reinterpret_cast<uint32_t*>(take(Q * 4));
+    sc.overflow = reinterpret_cast<int32_t*>(take(Q * 4));
+    sc.overflow_group = reinterpret_cast<int32_t*>(take(Q * 4));
+    sc.group_leaves = reinterpret_cast<int32_t*>(take((Q / 64) * kMaxGroupLeaves * 4));
+    sc.group_leaf_count = reinterpret_cast<int32_t*>(take((Q / 64) * 4));
+    sc.counter = reinterpret_cast<int32_t*>(take(256));
+    TK_REQUIRE(at < (size_t)TKHIP_STATIC_SCRATCH_BYTES, TKHIP_E_LIMIT, "tkhip_map_gather_static: scratch layout exceeds the array");
+    sc.sort_temp = base + at;
+    sc.sort_temp_bytes = (size_t)TKHIP_STATIC_SCRATCH_BYTES - at;
+    hipStream_t s = m->stream;
+    const size_t q = (size_t)nq;
+    QueryView qv{q4, q4 + q, q4 + 2 * q, q4 + 3 * q};
+    k_pack_queries<<<divup(nq, 256), 256, 0, s>>>(p, n, wo, R, radius2, q4, q4 + q, q4 + 2 * q, q4 + 3 * q, nq);
+    TK_LAUNCH_CHECK();
+    GatherOut out{};
+    out.flux = flux;
+    out.found = found;
+    out.r2out = radius2_out;
+    out.idx = idx;
+    if (idx) TK_HIP(hipMemsetAsync(idx, 0xff, q * (size_t)m->k * 4, s));
+    TK_TRY(map_gather_in(m, nq, qv, out, 0, false, sc));
+    TK_HIP(hipStreamSynchronize(s));
+    return TKHIP_OK;
 }
 
 int tkhip_pixel_update(tkhip_ctx* ctx, int64_t n, float* flux, float* photons, float* radius2, const float* lindir,

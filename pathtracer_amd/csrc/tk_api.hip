@@ -102,6 +102,7 @@ int tkhip_create(int device, tkhip_ctx** out) {
         return TKHIP_E_HIP;
     }
     int rc = upload_direction_tables(ctx);
+    if (!rc) rc = static_scratch_init(device);
     if (rc) { tkhip_destroy(ctx); return rc; }
     *out = ctx;
     return TKHIP_OK;

@@ -192,11 +192,18 @@ int sort_pairs_u64(hipStream_t stream, DevBuf& temp, uint64_t* kin, uint64_t* ko
                    size_t n, int end_bit);
 int sort_pairs_u32(hipStream_t stream, DevBuf& temp, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout,
                    size_t n, int end_bit);
+// The same sort in caller-provided scratch of temp_bytes (no allocation; TKHIP_E_LIMIT if too small),
+// and the scratch size a sort of n pairs needs.
+int sort_pairs_u32_in(hipStream_t stream, void* temp, size_t temp_bytes, uint32_t* kin, uint32_t* kout, uint32_t* vin,
+                      uint32_t* vout, size_t n, int end_bit);
+int sort_pairs_u32_temp_bytes(size_t n, int end_bit, size_t* bytes);
 // Grows `temp` to what sort_pairs_u32 of n pairs needs, without sorting.
 int sort_pairs_u32_reserve(DevBuf& temp, size_t n, int end_bit);
 int exclusive_scan_i32(hipStream_t stream, DevBuf& temp, const int32_t* in, int32_t* out, size_t n);
 
 int upload_direction_tables(tkhip_ctx* ctx);
+// Looks up the address of the library's static gather scratch on `device` (which must be current).
+int static_scratch_init(int device);
 void destroy_sppm(tkhip_ctx* ctx);
 
 }  // namespace tkd

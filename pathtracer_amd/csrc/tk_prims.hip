@@ -28,6 +28,24 @@ int sort_pairs_u32(hipStream_t stream, DevBuf& temp, uint32_t* kin, uint32_t* ko
     return sort_pairs_impl<uint32_t>(stream, temp, kin, kout, vin, vout, n, end_bit);
 }
 
+int sort_pairs_u32_temp_bytes(size_t n, int end_bit, size_t* bytes) {
+    *bytes = 0;
+    if (n == 0) return TKHIP_OK;
+    uint32_t* none = nullptr;
+    TK_HIP(rocprim::radix_sort_pairs(nullptr, *bytes, none, none, none, none, n, 0, end_bit, (hipStream_t) nullptr));
+    return TKHIP_OK;
+}
+
+int sort_pairs_u32_in(hipStream_t stream, void* temp, size_t temp_bytes, uint32_t* kin, uint32_t* kout, uint32_t* vin,
+                      uint32_t* vout, size_t n, int end_bit) {
+    if (n == 0) return TKHIP_OK;
+    size_t bytes = 0;
+    TK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, end_bit, stream));
+    TK_REQUIRE(bytes <= temp_bytes, TKHIP_E_LIMIT, "sort of %zu pairs needs %zu bytes of scratch, %zu given", n, bytes, temp_bytes);
+    TK_HIP(rocprim::radix_sort_pairs(temp, bytes, kin, kout, vin, vout, n, 0, end_bit, stream));
+    return TKHIP_OK;
+}
+
 int sort_pairs_u32_reserve(DevBuf& temp, size_t n, int end_bit) {
     if (n == 0) return TKHIP_OK;
     size_t bytes = 0;

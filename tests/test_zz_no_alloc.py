@@ -1,0 +1,65 @@
+"""tkhip_map_gather_static — the gather entry point that allocates nothing —
+against tkhip_map_gather on the same map and queries: two calls in a row, the
+second with fewer queries, through the C ABI (device pointers from torch)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import _abi
+from pathtracer_amd.tracer import Context, PhotonMap
+from tests.conftest import make_photons, make_queries
+from tests.ref_fixtures import bits_equal, sorted_idx
+
+pytestmark = pytest.mark.gpu
+
+
+def _static_gather(m, p, n, wo, R, r2, want_idx=True):
+    import torch
+    dev = [torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda() for a in (p, n, wo, R, r2)]
+    nq = len(r2)
+    flux = torch.full((nq, 3), -7.0, dtype=torch.float32, device="cuda")
+    found = torch.full((nq,), -7, dtype=torch.int32, device="cuda")
+    r2o = torch.full((nq,), -7.0, dtype=torch.float32, device="cuda")
+    idx = torch.full((nq, m.k), 12345, dtype=torch.int32, device="cuda") if want_idx else None
+    torch.cuda.synchronize()
+    rc = m.lib.tkhip_map_gather_static(m.h, nq, *[d.data_ptr() for d in dev], flux.data_ptr(), found.data_ptr(),
+                                       r2o.data_ptr(), idx.data_ptr() if idx is not None else None)
+    _abi.check(m.lib, rc, "tkhip_map_gather_static")
+    return (flux.cpu().numpy(), found.cpu().numpy(), r2o.cpu().numpy(),
+            sorted_idx(idx.cpu().numpy()) if idx is not None else None)
+
+
+def test_static_gather_matches_the_allocating_entry_point():
+    ctx = Context(0)
+    rng = np.random.default_rng(42)
+    k = 100
+    pos, power, th, ph = make_photons(rng, 60000)
+    m = PhotonMap(ctx, len(pos), k)
+    m.store(pos, power, th, ph)
+    m.build()
+    for nq in (30000, 7001):        # the second call is smaller: stale scratch of the first must not show
+        q = make_queries(rng, nq)
+        fl, fo, r2, idx = m.gather(*q, mode=0)
+        sfl, sfo, sr2, sidx = _static_gather(m, *q)
+        assert (sfo == fo).all()
+        assert bits_equal(sr2, r2)
+        assert (sidx == idx).all()
+        np.testing.assert_allclose(sfl, fl, rtol=1e-5, atol=1e-12)
+        assert (fo >= k).any() and (fo < k).any()       # both gather kernels took part
+    # beyond the stated maximum: a clear error, nothing run
+    import torch
+    z = torch.zeros(8, device="cuda")
+    rc = m.lib.tkhip_map_gather_static(m.h, 65537, *[z.data_ptr()] * 5, z.data_ptr(), z.data_ptr(), z.data_ptr(), None)
+    assert rc == -5 and b"at most" in m.lib.tkhip_last_error()
+    # a second map with another k on the same GPU shares the array
+    m2 = PhotonMap(ctx, 5000, 50)
+    p2 = make_photons(rng, 5000)
+    m2.store(*p2)
+    m2.build()
+    q = make_queries(rng, 900)
+    fl, fo, r2, idx = m2.gather(*q, mode=0)
+    sfl, sfo, sr2, sidx = _static_gather(m2, *q)
+    assert (sfo == fo).all() and bits_equal(sr2, r2) and (sidx == idx).all()
+    np.testing.assert_allclose(sfl, fl, rtol=1e-5, atol=1e-12)
+    m.close(); m2.close(); ctx.close()
