@@ -60,6 +60,8 @@ def lib():
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "orc_sppm_destroy": (None, [C.c_void_p]),
         "orc_sppm_set_jitter": (None, [C.c_void_p, C.c_int]),
+        "orc_sppm_set_tie_rule": (None, [C.c_void_p, C.c_int]),
+        "orc_map_set_tie_rule": (None, [C.c_void_p, C.c_int]),
         "orc_sppm_photon_pass": (None, [C.c_void_p, C.c_int, C.POINTER(_abi.TkIterStats)]),
         "orc_sppm_build_maps": (None, [C.c_void_p, C.POINTER(_abi.TkIterStats)]),
         "orc_sppm_camera_pass": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_abi.TkIterStats)]),
@@ -186,6 +188,9 @@ class OracleSppm:
 
     def set_jitter(self, on):
         lib().orc_sppm_set_jitter(self.h, 1 if on else 0)
+
+    def set_tie_rule(self, by_index):
+        lib().orc_sppm_set_tie_rule(self.h, 1 if by_index else 0)
 
     def photon_pass(self, it):
         st = _abi.TkIterStats()

@@ -1070,6 +1070,7 @@ struct orc_map {
     float cos_t[256], sin_t[256], cos_p[256], sin_p[256];
     box3 bbox;           /* stays empty in split_mode 0 (Union result discarded) */
     int built;
+    int tie_by_index;    /* among photons tied at the k-th distance keep the lowest indices (orc_map_set_tie_rule) */
 };
 
 /* src/tracer/Photonmap.cpp:26-33 */
@@ -1293,8 +1294,23 @@ static v3 map_radiance_estimate(const orc_map* m, v3 p, v3 n, v3 wo, v3 R, float
     if (m->built) neighbor_search(m, &np, 0, m->k);
     *radius2 = np.dist2[m->k];
     *found = np.found;
+    if (m->tie_by_index && np.found == m->k) {
+        /* The search keeps whichever of the photons tied at the k-th distance it met first; the
+         * contract of the GPU path is the lowest indices.  Same count, same radius, other members. */
+        const float kth = np.dist2[m->k];
+        int less = 0;
+        for (int i = 0; i < np.found; ++i) {
+            v3 dv = vsub(m->ph[np.nb[i]].pos, p);
+            if (vdot(dv, dv) < kth) np.nb[less++] = np.nb[i];
+        }
+        for (int64_t i = 0; i < m->n && less < m->k; ++i) {
+            v3 dv = vsub(m->ph[i].pos, p);
+            if (vdot(dv, dv) == kth) np.nb[less++] = (int32_t)i;
+        }
+    }
     return estimate_sum(m, np.nb, np.found, n, wo, R);
 }
+void orc_map_set_tie_rule(orc_map* m, int by_index) { m->tie_by_index = by_index; }
 void orc_map_gather(orc_map* m, int64_t nq, const float* p, const float* n, const float* wo,
                     const float* R, const float* radius2, float* flux, int32_t* found,
                     float* radius2_out, int32_t* idx) {
@@ -1768,6 +1784,7 @@ orc_sppm* orc_sppm_begin(orc_scene* s, const TkSppmParam* param, int max_depth, 
 }
 /* jitter = 0: the camera sampler is the reference's StratifiedSampler built with jitter = false. */
 void orc_sppm_set_jitter(orc_sppm* r, int jitter) { r->no_jitter = jitter ? 0 : 1; }
+void orc_sppm_set_tie_rule(orc_sppm* r, int by_index) { r->gmap->tie_by_index = by_index; r->cmap->tie_by_index = by_index; }
 void orc_sppm_destroy(orc_sppm* r) {
     if (!r) return;
     orc_map_destroy(r->gmap); orc_map_destroy(r->cmap);

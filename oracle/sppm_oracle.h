@@ -77,6 +77,11 @@ void orc_map_gather_brute(orc_map* m, int64_t nq, const float* p, const float* n
                           const float* wo, const float* R, const float* radius2, float* flux,
                           int32_t* found, float* radius2_out, int32_t* idx);
 int64_t orc_map_split_histogram(orc_map* m, int64_t hist[5]);
+/* by_index 1: among photons tied at the k-th distance orc_map_gather keeps the
+ * lowest indices (the GPU path's rule) instead of the ones the traversal met
+ * first (the reference's, src/tracer/neighbor.cpp:31-83).  Count and radius are
+ * the same either way. */
+void orc_map_set_tie_rule(orc_map* m, int by_index);
 
 /* --- full SPPM --- */
 /* rng_cost 0: counter-based RNG only.  rng_cost 1: additionally seeds and
@@ -89,6 +94,7 @@ orc_sppm* orc_sppm_begin(orc_scene* s, const TkSppmParam* param, int max_depth, 
 void orc_sppm_destroy(orc_sppm* r);
 /* jitter 0: stratum centres, as StratifiedSampler(x, y, jitter = false) (src/core/sampler.cpp:51, :61-62). */
 void orc_sppm_set_jitter(orc_sppm* r, int jitter);
+void orc_sppm_set_tie_rule(orc_sppm* r, int by_index);   /* orc_map_set_tie_rule for both maps */
 void orc_sppm_photon_pass(orc_sppm* r, int iter, TkIterStats* st);
 void orc_sppm_build_maps(orc_sppm* r, TkIterStats* st);
 /* y0,y1: restrict the camera pass to rows [y0,y1) (bounded CPU baseline sample);

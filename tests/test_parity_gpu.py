@@ -311,70 +311,80 @@ def _tracers(scene, W, gs, cs, iters, seed=0x5EED):
     osc = O.OracleScene(scene, W, W)
     orr = O.OracleSppm(osc, scene.sppm_param(globalSize=gs, causticSize=cs, numRecurse=iters), scene.tracer.max_depth,
                        scene.tracer.russian_roulette, seed, threads=8, split_mode=1, faithful_bvh=0)
+    orr.set_tie_rule(True)   # photons tied at the k-th distance: lowest index, as on the GPU
     return tr, osc, orr
 
 
-@pytest.mark.parametrize("name,cs", [("cornell_sphere.scene", 3000), ("cornell_box.scene", 0)])
+def _assert_pixels_equal(gpx, opx):
+    """SPPMPixel arrays of the GPU and of the oracle after the same iterations: Ld, photon counts
+    and radii bit for bit; the two fluxes within 1e-5 relative (the order of the sum over a gather's
+    photons differs), with an absolute floor of 1e-7 of the largest flux for near-black pixels."""
+    assert gpx.shape == opx.shape
+    g, o = gpx.view(np.uint32), opx.view(np.uint32)
+    assert (g[:, 0:3] == o[:, 0:3]).all(), "Ld"
+    assert (g[:, 9:13] == o[:, 9:13]).all(), "photon counts / radii"
+    for lo, hi in ((3, 6), (6, 9)):
+        a, b = gpx[:, lo:hi], opx[:, lo:hi]
+        assert (np.abs(a - b) <= 1e-5 * np.abs(b) + 1e-7 * np.abs(b).max()).all(), (lo, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("name,cs", [("cornell_sphere.scene", 3000), ("cornell_box.scene", 0), ("cornell_dragon.scene", 3000)])
 def test_photon_pass_matches_oracle(name, cs):
-    """Same Halton indices, same hashed random numbers: the path counts are equal and the photon arrays agree
-    except where a transcendental differs in its last bit (cos/sin of the disk mapping) and flips a decision."""
+    """tracePhoton / traceCausticPhoton with the same Halton indices and the same hashed random numbers: the
+    path counts and the photon arrays (positions, powers, direction bytes, in storage order) are equal bit
+    for bit."""
     scene = Scene.load(asset_scene(name))
     tr, osc, orr = _tracers(scene, 64, 20000, cs, 4)
     st = _abi.TkIterStats()
     tr.photon_pass(0, st)
     ost = orr.photon_pass(0)
     assert st.global_stored == 20000 and st.caustic_stored == cs
-    assert abs(st.global_paths - ost.global_paths) <= 3
-    if cs:
-        assert abs(st.caustic_paths - ost.caustic_paths) <= max(30, ost.caustic_paths // 500)
+    assert st.global_paths == ost.global_paths and st.caustic_paths == ost.caustic_paths
+    assert st.shoot_global == ost.shoot_global and st.shoot_caustic == ost.shoot_caustic
     for which, cap in ((0, 20000), (1, cs)):
         if cap == 0:
             continue
         gpos, gpow, gth, gph = tr.photons(which)
         opos, opow, oth, oph, _ = orr.photons(which, cap)
         assert len(gpos) == len(opos) == cap
-        # align by position through a nearest-neighbour match of the two sets (order can shift after a divergence)
-        key_g = {tuple(np.round(p, 4)): i for i, p in enumerate(gpos)}
-        match = [(key_g.get(tuple(np.round(p, 4)), -1), j) for j, p in enumerate(opos)]
-        pairs = np.array([(i, j) for i, j in match if i >= 0])
-        assert len(pairs) > 0.97 * cap
-        gi, oj = pairs[:, 0], pairs[:, 1]
-        assert np.abs(gpos[gi] - opos[oj]).max() < 2e-4
-        rel = np.abs(gpow[gi] - opow[oj]) / np.maximum(np.abs(opow[oj]), 1e-6)
-        assert np.median(rel) < 1e-5 and (rel < 1e-3).mean() > 0.99
-        assert (np.abs(gth[gi].astype(int) - oth[oj].astype(int)) <= 1).mean() > 0.99
+        assert (gpos.view(np.uint32) == opos.view(np.uint32)).all()
+        assert (gpow.view(np.uint32) == opow.view(np.uint32)).all()
+        assert (gth == oth).all() and (gph == oph).all()
     tr.close(); orr.close(); osc.close()
 
 
-def test_iterations_match_oracle_sphere_scene():
-    """Three full iterations (caustic + global maps): per-pixel SPPM state and the resolved image."""
-    scene = Scene.load(asset_scene("cornell_sphere.scene"))
-    W = 96
-    tr, osc, orr = _tracers(scene, W, 20000, 4000, 4)
+def test_encode_direction_matches_oracle(gpu_ctx):
+    """The two direction bytes (float acos / atan2, float products) on random and on awkward directions."""
+    rng = np.random.default_rng(3)
+    wo = rng.normal(size=(50000, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wo[:6] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [0, -1, 0], [-1, -1e-8, 0]]
+    wo[6] = [0, 0, np.float32(1.0000001)]                 # acos of a value just above one: NaN, clamped
+    th, ph = gpu_ctx.encode_directions(wo)
+    oth, oph = np.empty(len(wo), np.uint8), np.empty(len(wo), np.uint8)
+    for i in range(len(wo)):
+        a, b = C.c_uint8(), C.c_uint8()
+        L.orc_encode_direction(O.fp(wo[i]), C.byref(a), C.byref(b))
+        oth[i], oph[i] = a.value, b.value
+    assert (th == oth).all() and (ph == oph).all()
+
+
+@pytest.mark.parametrize("name,W,cs", [("cornell_sphere.scene", 96, 4000), ("cornell_dragon.scene", 128, 3000)])
+def test_iterations_match_oracle(name, W, cs):
+    """Three full iterations (photon passes, tree builds, camera pass with both gathers, update): counters
+    equal, per-pixel SPPM state equal (fluxes to 1e-5), resolved images equal to one level."""
+    scene = Scene.load(asset_scene(name))
+    tr, osc, orr = _tracers(scene, W, 20000, cs, 4)
     for it in range(3):
         st = tr.iteration()
         ost = orr.iteration(it)
-        assert st.global_stored == ost.global_stored and st.caustic_stored == ost.caustic_stored
-        assert abs(st.shoot_global - ost.shoot_global) <= 6 * (it + 1)
-        assert abs(st.gathers_global - ost.gathers_global) <= 0.01 * ost.gathers_global
-        assert abs(st.gathers_caustic - ost.gathers_caustic) <= 0.01 * ost.gathers_caustic
-        assert abs(st.gather_photons - ost.gather_photons) <= 0.01 * ost.gather_photons
-    gpx, opx = tr.pixels(), orr.pixels()
-    # Ld (direct + emitted): identical sampling, fp32 agreement on nearly every pixel
-    close = np.abs(gpx[:, :3] - opx[:, :3]) <= 1e-4 * np.maximum(np.abs(opx[:, :3]), 1e-3)
-    assert close.mean() > 0.995
-    for lo, hi in ((3, 6), (6, 9), (9, 10), (10, 11), (11, 12), (12, 13)):
-        a, b = gpx[:, lo:hi], opx[:, lo:hi]
-        ok = np.abs(a - b) <= 1e-3 * np.maximum(np.abs(b), 1e-6)
-        assert ok.mean() > 0.97, (lo, ok.mean())          # the rest sit next to a photon whose path diverged
-        assert abs(a.mean() - b.mean()) <= 5e-3 * abs(b.mean())
-    gi, oi = tr.resolve().astype(np.float32), orr.resolve().astype(np.float32)
-    rmse = float(np.sqrt(((gi - oi) ** 2).mean()))
-    assert rmse < 1.5, rmse                               # RMSE on the 0..255 scale at matched iterations and seeds
-    assert (np.abs(gi - oi) <= 1).mean() > 0.97
-    sg, sc_, nr = tr.counters()
-    osg, osc_, onr = orr.counters()
-    assert nr == onr == 4 and abs(sg - osg) <= 20 and abs(sc_ - osc_) <= 0.01 * osc_
+        for f in ("global_stored", "caustic_stored", "global_paths", "caustic_paths", "shoot_global", "shoot_caustic",
+                  "gathers_global", "gathers_caustic", "gather_photons"):
+            assert getattr(st, f) == getattr(ost, f), (it, f, getattr(st, f), getattr(ost, f))
+        _assert_pixels_equal(tr.pixels(), orr.pixels())
+    gi, oi = tr.resolve().astype(int), orr.resolve().astype(int)
+    assert np.abs(gi - oi).max() <= 1 and (gi == oi).mean() > 0.999      # powf may differ in its last bit
+    assert tr.counters() == orr.counters()
     tr.close(); orr.close(); osc.close()
 
 
@@ -394,19 +404,14 @@ def test_odd_image_size_matches_oracle():
         st = tr.iteration()
         ost = orr.iteration(it)
         assert st.global_stored == ost.global_stored == 6000
-        assert abs(st.gathers_global - ost.gathers_global) <= 0.02 * ost.gathers_global + 2
+        assert st.gathers_global == ost.gathers_global and st.gathers_caustic == ost.gathers_caustic
     gpx, opx = tr.pixels(), orr.pixels()
     assert gpx.shape == opx.shape == (W * H, 13)
     assert (gpx[:, 12] <= np.float32(0.08)).all()
-    seen = (gpx[:, 10] > 0).reshape(H, W)
-    oseen = (opx[:, 10] > 0).reshape(H, W)
-    assert (seen == oseen).mean() > 0.99                                     # the same pixels gathered, up to the last row and column
-    assert (seen[-1] == oseen[-1]).mean() > 0.9 and (seen[:, -1] == oseen[:, -1]).mean() > 0.9
-    close = np.abs(gpx[:, :3] - opx[:, :3]) <= 1e-4 * np.maximum(np.abs(opx[:, :3]), 1e-3)
-    assert close.mean() > 0.99
-    gi, oi = tr.resolve().astype(np.float32), orr.resolve().astype(np.float32)
+    _assert_pixels_equal(gpx, opx)
+    gi, oi = tr.resolve().astype(int), orr.resolve().astype(int)
     assert gi.shape == (H, W, 3)
-    assert float(np.sqrt(((gi - oi) ** 2).mean())) < 3.0
+    assert np.abs(gi - oi).max() <= 1
     tr.close(); orr.close(); osc.close()
 
 
@@ -464,22 +469,6 @@ def test_resolve_matches_oracle():
     gimg = tr.resolve()
     assert np.abs(gimg.astype(int) - oimg.astype(int)).max() <= 1      # powf may differ in its last bit
     assert (gimg == oimg).mean() > 0.99
-    tr.close(); orr.close(); osc.close()
-
-
-def test_dragon_iteration_statistics(dragon_scene):
-    """The benchmark scene at reduced size: counts and image level against the oracle."""
-    W = 128
-    tr, osc, orr = _tracers(dragon_scene, W, 20000, 3000, 4)
-    for it in range(2):
-        st = tr.iteration()
-        ost = orr.iteration(it)
-        assert abs(st.global_paths - ost.global_paths) <= 0.01 * ost.global_paths
-        assert abs(st.caustic_paths - ost.caustic_paths) <= 0.03 * ost.caustic_paths
-        assert abs(st.gathers_global - ost.gathers_global) <= 0.01 * ost.gathers_global
-    gi, oi = tr.resolve().astype(np.float32), orr.resolve().astype(np.float32)
-    assert abs(gi.mean() - oi.mean()) < 0.5
-    assert float(np.sqrt(((gi - oi) ** 2).mean())) < 6.0
     tr.close(); orr.close(); osc.close()
 
 
