@@ -199,33 +199,50 @@ __global__ void k_permute(const float* pos, const float* pow, const uint16_t* di
                           __uint_as_float((uint32_t)dir[s]));
 }
 
-__global__ void k_leaf_boxes(const float4* pos4, float4* node_box, int64_t n, int nl, int depth) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nl) return;
-    int64_t s = leaf_start(j, n, depth), e = leaf_start(j + 1, n, depth);
+// Tight box of every leaf: kLeafCap lanes per leaf, one photon per lane (coalesced), then a
+// butterfly reduction inside the kLeafCap lanes.
+static_assert(kLeafCap == 32, "k_leaf_boxes reduces over 32-lane halves of a wave");
+__global__ void __launch_bounds__(256) k_leaf_boxes(const float4* pos4, float4* node_box, int64_t n, int nl, int depth) {
+    const int64_t j = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kLeafCap;
+    const int ph = threadIdx.x % kLeafCap;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = s; i < e; ++i) {
-        float4 p = pos4[i];
-        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-    }
-    int node = nl + j;
-    node_box[2 * (int64_t)node] = make_float4(mn[0], mn[1], mn[2], mx[0]);
-    node_box[2 * (int64_t)node + 1] = make_float4(mx[1], mx[2], 0.f, 0.f);
-}
-// Boxes of the inner nodes, level by level from the leaves' parents to the
-// root, by one block (a level is at most nl / 2 nodes of a few thousand).
-__global__ void __launch_bounds__(1024) k_inner_boxes(float4* node_box, int depth) {
-    for (int level = depth - 1; level >= 0; --level) {
-        const int count = 1 << level;
-        for (int j = threadIdx.x; j < count; j += blockDim.x) {
-            const int64_t node = count + j;
-            float4 a0 = node_box[4 * node], a1 = node_box[4 * node + 1];
-            float4 b0 = node_box[4 * node + 2], b1 = node_box[4 * node + 3];
-            node_box[2 * node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
-            node_box[2 * node + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), 0.f, 0.f);
+    if (j < nl) {
+        const int64_t s = leaf_start(j, n, depth), e = leaf_start(j + 1, n, depth);
+        if (s + ph < e) {
+            const float4 p = pos4[s + ph];
+            mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z;
         }
+    }
+    for (int o = kLeafCap / 2; o > 0; o >>= 1)
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        }
+    if (j < nl && ph == 0) {
+        const int64_t node = nl + j;
+        node_box[2 * node] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+        node_box[2 * node + 1] = make_float4(mx[1], mx[2], 0.f, 0.f);
+    }
+}
+// Boxes of the inner nodes, level by level from the leaves' parents to the root.  A level of
+// more than kWideLevel nodes gets a launch of its own; the narrow levels above are done by one
+// block, which needs no launch per level.
+constexpr int kWideLevel = 4096;
+TKD void inner_box(float4* node_box, int64_t node) {
+    float4 a0 = node_box[4 * node], a1 = node_box[4 * node + 1];
+    float4 b0 = node_box[4 * node + 2], b1 = node_box[4 * node + 3];
+    node_box[2 * node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
+    node_box[2 * node + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256) k_inner_level(float4* node_box, int level) {
+    const int count = 1 << level;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) inner_box(node_box, (int64_t)count + j);
+}
+__global__ void __launch_bounds__(1024) k_inner_boxes(float4* node_box, int top_level) {
+    for (int level = top_level; level >= 0; --level) {
+        const int count = 1 << level;
+        for (int j = threadIdx.x; j < count; j += blockDim.x) inner_box(node_box, (int64_t)count + j);
         __syncthreads();
     }
 }
@@ -935,8 +952,11 @@ int map_build(tkhip_map* m) {
     }
     k_permute<<<divup(n, B), B, 0, s>>>(pos, m->in_pow.as<float>(), m->in_dir.as<uint16_t>(), m->idx_a.as<uint32_t>(),
                                         m->pos4.as<float4>(), m->pow4.as<float4>(), n);
-    k_leaf_boxes<<<divup(nl, 64), 64, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl, depth);
-    if (depth > 0) k_inner_boxes<<<1, 1024, 0, s>>>(m->node_box.as<float4>(), depth);
+    k_leaf_boxes<<<divup((int64_t)nl * kLeafCap, 256), 256, 0, s>>>(m->pos4.as<float4>(), m->node_box.as<float4>(), n, nl, depth);
+    int level = depth - 1;
+    for (; level >= 0 && (1 << level) > kWideLevel; --level)
+        k_inner_level<<<divup(1 << level, 256), 256, 0, s>>>(m->node_box.as<float4>(), level);
+    if (level >= 0) k_inner_boxes<<<1, 1024, 0, s>>>(m->node_box.as<float4>(), level);
     TK_LAUNCH_CHECK();
     m->built = true;
     return TKHIP_OK;

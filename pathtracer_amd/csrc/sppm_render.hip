@@ -766,6 +766,12 @@ static int read_u64_counter(Lane& l, int at, int64_t* out) {
     return TKHIP_OK;
 }
 
+// Largest batch of light paths: 16 M, and no more than 4 GiB of photon staging (32 bytes per slot;
+// a scene that yields few photons per path would otherwise ask for batches of 10 GB and more).
+static int64_t photon_batch_cap(int slots) {
+    return std::min<int64_t>((int64_t)1 << 24, ((int64_t)1 << 32) / (32 * (int64_t)std::max(slots, 1)));
+}
+
 // Enqueues one batch of light paths of a photon pass on its lane: the path
 // kernel, the scan over the per-path photon counts, the scatter into the local
 // store and the read-back of the batch counters.  Nothing is waited for.
@@ -780,7 +786,7 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     int32_t* counters = ln.counters.as<int32_t>();
     const int64_t need = quota - stored;
     int64_t B = (int64_t)((double)need / s->yield[KIND] * 1.02) + 256;
-    B = std::min<int64_t>(B, (int64_t)1 << 24);
+    B = std::min<int64_t>(B, photon_batch_cap(slots));
     TK_TRY(ln.stage_pos.ensure((size_t)B * slots * 16));
     TK_TRY(ln.stage_pow.ensure((size_t)B * slots * 16));
     TK_TRY(ln.rec_count.ensure((size_t)B * 4));
@@ -844,7 +850,10 @@ static int photon_pass_finish(tkhip_ctx* ctx, int64_t B) {
     Lane& ln = s->lane[KIND];
     const int64_t quota = s->quota[KIND];
     int64_t stored = 0, shot = 0;
-    const int64_t emitted_cap = KIND == 0 ? (int64_t)1 << 40 : quota * 4000 + 100000;
+    // "Emit until the map is full" never ends in a scene that cannot take photons (no diffuse surface
+    // in reach for the global map, nothing specular for the caustic map): both passes give up after
+    // 4000 paths per photon asked for.
+    const int64_t emitted_cap = quota * 4000 + 100000;
     while (B > 0) {
         TK_HIP(hipStreamSynchronize(ln.stream));
         const int64_t need = quota - stored;
@@ -864,6 +873,9 @@ static int photon_pass_finish(tkhip_ctx* ctx, int64_t B) {
     s->n_loc[KIND] = stored;
     s->last_shot[KIND] = shot;
     s->local_shot[KIND] += shot;
+    TK_REQUIRE(!(KIND == 0 && stored == 0 && quota > 0), TKHIP_E_STATE,
+               "photon pass: %lld light paths stored no photon for the global map (no diffuse surface in reach of the lights)",
+               (long long)shot);
     return TKHIP_OK;
 }
 
@@ -1060,6 +1072,43 @@ static void fill_photon_stats(SppmState* s, TkIterStats* st) {
 
 using namespace tkd;
 
+// Last part of tkhip_sppm_begin: the first uploads and warm-up launches.  On failure the caller
+// synchronises and destroys the state.
+static int sppm_begin_launches(tkhip_ctx* ctx, SppmState* s, const std::vector<int32_t>& rows, float radius2) {
+    if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_init_planes<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, radius2);
+    TK_LAUNCH_CHECK();
+    // One launch of each path kernel on an empty queue (the counters are zero): the first launch of a
+    // kernel loads its code and sets up the scratch memory its register spills need, milliseconds
+    // that would otherwise fall into the first iteration.
+    {
+        PhotonArgs pa{};
+        pa.sc = ctx->scene;
+        CameraArgs ca{};
+        ca.sc = ctx->scene; ca.cam = ctx->cam;
+        k_photon_paths<0><<<s->path_waves[0], kPathBlock, 0, s->lane[0].stream>>>(pa, s->lane[0].counters.as<int32_t>());
+        k_photon_paths<1><<<s->path_waves[1], kPathBlock, 0, s->lane[1].stream>>>(pa, s->lane[1].counters.as<int32_t>());
+        k_camera_paths<<<s->path_waves[2], kPathBlock, 0, s->lane[2].stream>>>(ca, 1, s->lane[2].counters.as<int32_t>());
+        TK_LAUNCH_CHECK();
+        // likewise the scan and the sort of the library the passes use (their first call is slow)
+        for (int w = 0; w < 2; ++w) {
+            Lane& ln = s->lane[w];
+            if (s->quota[w] <= 0) continue;
+            TK_HIP(hipMemsetAsync(ln.rec_count.p, 0, 256 * 4, ln.stream));   // the staging holds at least 256 paths
+            TK_TRY(exclusive_scan_i32(ln.stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), 256));
+            tkhip_map* m = s->map[w];
+            if (m->cap >= 2048) {
+                TK_HIP(hipMemsetAsync(m->key_a.p, 0, 2048 * 4, m->stream));
+                TK_TRY(sort_pairs_u32(m->stream, m->prim_temp, m->key_a.as<uint32_t>(), m->key_b.as<uint32_t>(), m->idx_a.as<uint32_t>(),
+                                      m->idx_b.as<uint32_t>(), 2048, 30));
+            }
+        }
+    }
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    for (Lane& l : s->lane) TK_HIP(hipStreamSynchronize(l.stream));
+    return TKHIP_OK;
+}
+
 #define TK_CTX_SPPM(ctx, fn)                                                             \
     TK_REQUIRE((ctx) != nullptr, TKHIP_E_ARG, fn ": null context");                      \
     TK_REQUIRE((ctx)->sppm != nullptr, TKHIP_E_STATE, fn ": call tkhip_sppm_begin first"); \
@@ -1151,8 +1200,8 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
         if (!rc) rc = map_reserve_queries(s->map[w], std::max<int64_t>(s->n_slots, 1));
         if (s->quota[w] <= 0) continue;
         Lane& ln = s->lane[w];
-        const size_t B = (size_t)std::min<int64_t>((int64_t)((double)s->quota[w] / s->yield[w] * 1.02) + 256, (int64_t)1 << 24);
         const size_t slots = w == 0 ? (size_t)max_depth : 1;
+        const size_t B = (size_t)std::min<int64_t>((int64_t)((double)s->quota[w] / s->yield[w] * 1.02) + 256, photon_batch_cap((int)slots));
         for (DevBuf* b : {&ln.stage_pos, &ln.stage_pow})
             if (!rc) rc = b->ensure(B * slots * 16);
         for (DevBuf* b : {&ln.rec_count, &ln.rec_offset})
@@ -1161,37 +1210,14 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
             if (!rc) rc = b->ensure(B * 16);
     }
     if (rc) { destroy_sppm(ctx); return rc; }
-    if (!rows.empty()) TK_HIP(hipMemcpyAsync(s->rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    k_init_planes<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, param->radius2);
-    TK_LAUNCH_CHECK();
-    // One launch of each path kernel on an empty queue (the counters are zero): the first launch of a
-    // kernel loads its code and sets up the scratch memory its register spills need, milliseconds
-    // that would otherwise fall into the first iteration.
-    {
-        PhotonArgs pa{};
-        pa.sc = ctx->scene;
-        CameraArgs ca{};
-        ca.sc = ctx->scene; ca.cam = ctx->cam;
-        k_photon_paths<0><<<s->path_waves[0], kPathBlock, 0, s->lane[0].stream>>>(pa, s->lane[0].counters.as<int32_t>());
-        k_photon_paths<1><<<s->path_waves[1], kPathBlock, 0, s->lane[1].stream>>>(pa, s->lane[1].counters.as<int32_t>());
-        k_camera_paths<<<s->path_waves[2], kPathBlock, 0, s->lane[2].stream>>>(ca, 1, s->lane[2].counters.as<int32_t>());
-        TK_LAUNCH_CHECK();
-        // likewise the scan and the sort of the library the passes use (their first call is slow)
-        for (int w = 0; w < 2; ++w) {
-            Lane& ln = s->lane[w];
-            if (s->quota[w] <= 0) continue;
-            TK_HIP(hipMemsetAsync(ln.rec_count.p, 0, 256 * 4, ln.stream));   // the staging holds at least 256 paths
-            TK_TRY(exclusive_scan_i32(ln.stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), 256));
-            tkhip_map* m = s->map[w];
-            if (m->cap >= 2048) {
-                TK_HIP(hipMemsetAsync(m->key_a.p, 0, 2048 * 4, m->stream));
-                TK_TRY(sort_pairs_u32(m->stream, m->prim_temp, m->key_a.as<uint32_t>(), m->key_b.as<uint32_t>(), m->idx_a.as<uint32_t>(),
-                                      m->idx_b.as<uint32_t>(), 2048, 30));
-            }
-        }
+    rc = sppm_begin_launches(ctx, s, rows, param->radius2);
+    if (rc != TKHIP_OK) {
+        // nothing half-initialised stays behind: wait for what was enqueued, then drop the state
+        (void)hipStreamSynchronize(ctx->stream);
+        for (Lane& l : s->lane) if (l.stream) (void)hipStreamSynchronize(l.stream);
+        destroy_sppm(ctx);
+        return rc;
     }
-    TK_HIP(hipStreamSynchronize(ctx->stream));
-    for (Lane& l : s->lane) TK_HIP(hipStreamSynchronize(l.stream));
     return TKHIP_OK;
 }
 
@@ -1202,7 +1228,12 @@ int tkhip_sppm_photon_begin(tkhip_ctx* ctx, int iter) {
     TK_REQUIRE(!s->photon_begun, TKHIP_E_STATE, "tkhip_sppm_photon_begin: a photon pass is already in flight");
     s->caustic_hoff = s->local_shot[0];
     TK_TRY(photon_pass_begin<0>(ctx, &s->begun_batch[0]));      // both passes are in flight together
-    TK_TRY(photon_pass_begin<1>(ctx, &s->begun_batch[1]));
+    int rc1 = photon_pass_begin<1>(ctx, &s->begun_batch[1]);
+    if (rc1 != TKHIP_OK) {   // no batch stays in flight behind an error
+        (void)hipStreamSynchronize(s->lane[0].stream);
+        (void)hipStreamSynchronize(s->lane[1].stream);
+        return rc1;
+    }
     s->photon_begun = true;
     return TKHIP_OK;
 }
@@ -1323,7 +1354,14 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     s->caustic_hoff = s->local_shot[0];
     int64_t Bg = 0, Bc = 0;
     TK_TRY(photon_pass_begin<0>(ctx, &Bg));
-    TK_TRY(photon_pass_begin<1>(ctx, &Bc));
+    {
+        int rc1 = photon_pass_begin<1>(ctx, &Bc);
+        if (rc1 != TKHIP_OK) {   // no batch stays in flight behind an error
+            (void)hipStreamSynchronize(s->lane[0].stream);
+            (void)hipStreamSynchronize(s->lane[1].stream);
+            return rc1;
+        }
+    }
     Worker wg, wc;
     wg.start(ctx, [&, ctx, s]() {
         TK_TRY(photon_pass_finish<0>(ctx, Bg));

@@ -475,7 +475,7 @@ def test_resolve_matches_oracle():
 @pytest.mark.parametrize("world", [2, 3])
 def test_rank_sharding_on_one_gpu(world):
     """Every rank of a world of 2 (3: quotas with a remainder) as a context of its own on this GPU, exchange by hand:
-    the merged pixel state equals the oracle's for the same sharding up to the usual divergent paths."""
+    the pixel state of every rank's rows equals the oracle's for the same sharding (fluxes to 1e-5)."""
     import torch
     from pathtracer_amd import distributed as D
     scene = Scene.load(asset_scene("cornell_sphere.scene"))
@@ -484,6 +484,8 @@ def test_rank_sharding_on_one_gpu(world):
     bes = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, world, 0) for r in range(world)]
     osc = O.OracleScene(scene, W, W)
     ors = [O.OracleSppm(osc, prm, 20, 0.8, 0x5EED, rank=r, world=world, threads=4) for r in range(world)]
+    for o in ors:
+        o.set_tie_rule(True)
     for it in range(2):
         for be, orc in zip(bes, ors):
             be.photon_begin(it)        # light paths enqueued first, camera paths traced beside them,
@@ -499,7 +501,7 @@ def test_rank_sharding_on_one_gpu(world):
                 be.set_map(which, cat[0], cat[1], cat[2], size, shot)
             op = [o.photons(which, size) for o in ors]
             oshot = sum(p[4] for p in op)
-            assert abs(shot - oshot) <= max(4, 0.01 * oshot)
+            assert shot == oshot
             for o in ors:
                 o.set_map_photons(which, np.concatenate([p[0] for p in op]), np.concatenate([p[1] for p in op]),
                                   np.concatenate([p[2] for p in op]), np.concatenate([p[3] for p in op]), oshot)
@@ -512,9 +514,8 @@ def test_rank_sharding_on_one_gpu(world):
     for r in range(world):
         mine, other = owner == r, owner != r
         assert (planes[r][:11, other] == 0).all() and (planes[r][11:, other] == np.float32(0.08)).all()
-        a, b = planes[r][:, mine], oplanes[r][:, mine]
-        ok = np.abs(a - b) <= 1e-3 * np.maximum(np.abs(b), 1e-6)
-        assert ok.mean() > 0.95
+        a, b = planes[r][:, mine].reshape(13, -1).T, oplanes[r][:, mine].reshape(13, -1).T
+        _assert_pixels_equal(np.ascontiguousarray(a), np.ascontiguousarray(b))
     # import / export round trip and resolve on the merged state
     merged = planes[0].copy()
     for r in range(1, world):
