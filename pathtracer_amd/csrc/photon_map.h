@@ -34,7 +34,7 @@ struct GatherOut {
 struct GatherScratch {
     uint32_t *q_keys_a, *q_keys_b, *q_vals_a, *q_order;
     int32_t *overflow, *overflow_group, *group_leaves, *group_leaf_count;
-    int32_t* counter;            // 1 int, cleared per gather
+    int32_t* counter;            // 128 ints, cleared per gather: [0] hand-over count, [32] work cursor
     void* sort_temp;
     size_t sort_temp_bytes;
 };

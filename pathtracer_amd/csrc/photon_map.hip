@@ -665,15 +665,20 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
 // (no selection is needed: found < k keeps them all and leaves the radius
 // unchanged); the rest go to the per-query kernel.
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 template <bool WANT_IDX>
 __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, const uint32_t* order, int64_t nq,
                                                       GatherOut out, int32_t* overflow, int32_t* overflow_count,
-                                                      GroupLeaves gl) {
+                                                      int32_t* work_cursor, GroupLeaves gl) {
     constexpr int FCAP = 64 * kLeavesPerStep;
     __shared__ float s_tab[1024];
-    __shared__ float4 s_pos[4][64];   // x, y, z, original index
-    __shared__ float4 s_dir[4][64];   // wi, power.r
-    __shared__ float2 s_pow[4][64];   // power.g, power.b
+    // candidates of the current step, struct of arrays so that four of them load as one float4
+    __shared__ __align__(16) float s_x[4][64];
+    __shared__ __align__(16) float s_y[4][64];
+    __shared__ __align__(16) float s_z[4][64];
+    __shared__ float4 s_rec[4][64][2];   // (wi.xyz, power.r) (power.g, power.b, original index, -)
     __shared__ int s_front[4][2][FCAP];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
     __syncthreads();
@@ -684,7 +689,13 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
     const int64_t ngroups = (nq + 63) >> 6;
     int (*front)[FCAP] = s_front[wave];
     unsigned long long found_sum = 0, staged_sum = 0;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
+    while (true) {
+        // groups are handed out one at a time: the waves of the grid (sized to what the GPU holds at
+        // once) stay busy until the last group is taken
+        int gi = 0;
+        if (lane == 0) gi = atomicAdd(work_cursor, 1);
+        const int64_t g = (int64_t)uniform_i(gi);
+        if (g >= ngroups) break;
         const int64_t slot = g * 64 + lane;
         const bool valid = slot < nq;
         const int64_t q = valid ? (int64_t)order[slot] : 0;
@@ -740,9 +751,15 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
             // A wave that would have to stream far more leaves than its neighbours (its queries straddle
             // two surfaces, or one of them still has a large radius) would hold up the whole launch.
             if (fcount > kMaxGroupLeaves) spread = true;
-            // 2. the photons of those leaves, a step at a time, next step's loads in flight
+            // 2. the photons of those leaves, a step of kLeavesPerStep leaves at a time (one photon per
+            //    lane, lane = leaf_slot * kLeafCap + photon), the next step's loads in flight.  A step has
+            //    two phases.  A: every lane runs all staged positions against its own query with the exact
+            //    distance rule and keeps the outcome as a bit mask: the positions come four at a time as
+            //    LDS broadcasts and the arithmetic is on 4-vectors (packed instructions), the sign of
+            //    dist2 - radius2 is shifted into the mask.  B: every lane walks the set bits of its mask
+            //    and adds those photons' contributions: a tenth of the candidates, so the per-photon
+            //    shading work is done for the accepted ones only.
             if (!spread && fcount > 0) {
-                // a step serves kLeavesPerStep leaves, one photon per lane (lane = leaf_slot * kLeafCap + photon)
                 auto fetch = [&](int i, float4* pp, float4* pw) {
                     bool has = false;
                     if (i + leaf_slot < fcount) {
@@ -755,32 +772,76 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
                 };
                 float4 pp = make_float4(0, 0, 0, 0), pw = pp;
                 bool has = fetch(0, &pp, &pw);
+                // negated query position and radius as pairs: dist2 - radius2 is sums and products of pairs
+                const f2v nqx = {-Q.p.x, -Q.p.x}, nqy = {-Q.p.y, -Q.p.y}, nqz = {-Q.p.z, -Q.p.z}, nr2 = {-Q.r2, -Q.r2};
+                // The normal turned to the side wo is on: f() is non-zero when wi and wo are on one side
+                // of the surface, which then reads wi . nw > 0, and |wi . n| = wi . nw there.
+                const float sgn = Q.won > 0.f ? 1.f : (Q.won < 0.f ? -1.f : 0.f);
+                const float nwx = Q.n.x * sgn, nwy = Q.n.y * sgn, nwz = Q.n.z * sgn;
+                const float* const lx = s_x[wave];
+                const float* const ly = s_y[wave];
+                const float* const lz = s_z[wave];
                 for (int i = 0; i < fcount; i += kLeavesPerStep) {
                     const unsigned long long staged = __ballot(has);
                     const int n_in = __popcll(staged);
+                    const int n4 = (n_in + 3) & ~3;
                     __builtin_amdgcn_wave_barrier();      // the previous step has been read by every lane
                     if (has) {
                         const int at = __popcll(staged & lt_mask);
                         F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
-                        s_pos[wave][at] = pp;
-                        s_dir[wave][at] = make_float4(wi.x, wi.y, wi.z, pw.x);
-                        s_pow[wave][at] = make_float2(pw.y, pw.z);
+                        s_x[wave][at] = pp.x; s_y[wave][at] = pp.y; s_z[wave][at] = pp.z;
+                        s_rec[wave][at][0] = make_float4(wi.x, wi.y, wi.z, pw.x);
+                        s_rec[wave][at][1] = make_float4(pw.y, pw.z, pp.w, 0.f);
+                    } else {
+                        // the slots up to the next multiple of four hold a position no query accepts
+                        const int at = n_in + __popcll(~staged & lt_mask);
+                        if (at < n4) { s_x[wave][at] = INFINITY; s_y[wave][at] = 0.f; s_z[wave][at] = 0.f; }
                     }
                     __builtin_amdgcn_wave_barrier();
                     has = i + kLeavesPerStep < fcount ? fetch(i + kLeavesPerStep, &pp, &pw) : false;
                     staged_sum += (unsigned long long)n_in;
-#pragma unroll 4
-                    for (int c = 0; c < n_in; ++c) {
-                        const float4 P = s_pos[wave][c], D = s_dir[wave][c];   // LDS broadcasts
-                        const float2 Wp = s_pow[wave][c];
-                        const float dx = P.x - Q.p.x, dy = P.y - Q.p.y, dz = P.z - Q.p.z;
-                        const bool acc = (dx * dx + dy * dy + dz * dz) < Q.r2;      // the exact rule, strict
-                        const float cs = D.x * Q.n.x + D.y * Q.n.y + D.z * Q.n.z;
-                        const float wgt = (acc && Q.won * cs > 0) ? fabsf(cs) : 0.f;
-                        if (WANT_IDX) { if (acc && cnt < k) out.idx[q * k + cnt] = __float_as_int(P.w); }
-                        cnt += acc ? 1 : 0;
-                        sx = fmaf(D.w, wgt, sx); sy = fmaf(Wp.x, wgt, sy); sz = fmaf(Wp.y, wgt, sz);
+                    // A: candidate c ends up at bit n4 - 1 - c of the 64-bit mask (m1 : m0)
+                    uint32_t m0 = 0, m1 = 0;
+                    for (int c = 0; c < n4; c += 4) {
+                        const f4v X = *reinterpret_cast<const f4v*>(lx + c);
+                        const f4v Y = *reinterpret_cast<const f4v*>(ly + c);
+                        const f4v Z = *reinterpret_cast<const f4v*>(lz + c);
+                        const f2v dx0 = X.xy + nqx, dy0 = Y.xy + nqy, dz0 = Z.xy + nqz;
+                        const f2v dx1 = X.zw + nqx, dy1 = Y.zw + nqy, dz1 = Z.zw + nqz;
+                        const f2v t0 = (dx0 * dx0 + dy0 * dy0 + dz0 * dz0) + nr2;   // negative: inside (the exact rule, strict)
+                        const f2v t1 = (dx1 * dx1 + dy1 * dy1 + dz1 * dz1) + nr2;
+                        m1 = __builtin_amdgcn_alignbit(m1, m0, 28);
+                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t0.x), 31);
+                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t0.y), 31);
+                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t1.x), 31);
+                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t1.y), 31);
                     }
+                    int wr = cnt;
+                    cnt += __popc(m0) + __popc(m1);
+                    if (!WANT_IDX && cnt >= k) { m0 = 0; m1 = 0; }   // handed on: its sum is not needed
+                    // B: the set bits of m1 (the first n4 - 32 candidates of a step of more than 32), then of
+                    // m0, highest first, i.e. in staging order.  A lane without bits left reads slot 0 and
+                    // adds nothing.
+                    const float4* const rec = &s_rec[wave][0][0];
+                    auto drain = [&](uint32_t w, int n_half, int first) {
+                        while (__any(w != 0)) {
+                            const bool live = w != 0;
+                            const int lzc = __clz(w);
+                            w &= ~(0x80000000u >> (lzc & 31));
+                            const int at = live ? first + lzc + n_half - 32 : 0;   // bit b is candidate n_half - 1 - b of this half
+                            const float4 D = rec[2 * at];
+                            const float2 Wp = *reinterpret_cast<const float2*>(&rec[2 * at + 1]);
+                            const float cs = fmaf(D.x, nwx, fmaf(D.y, nwy, D.z * nwz));
+                            const float wgt = live ? fmaxf(cs, 0.f) : 0.f;
+                            sx = fmaf(D.w, wgt, sx); sy = fmaf(Wp.x, wgt, sy); sz = fmaf(Wp.y, wgt, sz);
+                            if (WANT_IDX) {
+                                if (live && wr < k) out.idx[q * k + wr] = __float_as_int(rec[2 * at + 1].z);
+                                wr += live ? 1 : 0;
+                            }
+                        }
+                    };
+                    if (n4 > 32) { drain(m1, n4 - 32, 0); drain(m0, 32, n4 - 32); }
+                    else drain(m0, n4, 0);
                 }
             }
         }
@@ -833,7 +894,7 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
     int rc = m->in_pos.ensure(c * 12);
     if (!rc) rc = m->in_pow.ensure(c * 12);
     if (!rc) rc = m->in_dir.ensure(c * 2);
-    if (!rc) rc = m->counters.ensure(64);
+    if (!rc) rc = m->counters.ensure(512);
     if (!rc) rc = m->totals.ensure(32);
     if (!rc && hipMemset(m->totals.p, 0, 32) != hipSuccess) { set_error("map_create: memset failed"); rc = TKHIP_E_HIP; }
     if (!rc && (hipEventCreate(&m->ev_begin) != hipSuccess || hipEventCreate(&m->ev_end) != hipSuccess)) {
@@ -1027,6 +1088,24 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
     return map_gather_in(m, nq, qv, out, mode, timed, sc);
 }
 
+// Blocks of the grouped kernel that one GPU holds at once (its waves fetch their groups from a cursor).
+static int group_grid_blocks(int device) {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64) return 256 * 8;
+    if (cached[device] == 0) {
+        hipDeviceProp_t prop{};
+        int per_cu = 0;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gather_group<false>, 256, 0) != hipSuccess || per_cu < 1)
+            cached[device] = 256 * 8;
+        else
+            cached[device] = std::max(prop.multiProcessorCount, 1) * per_cu;
+    }
+    return cached[device];
+}
+
 int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed,
                   const GatherScratch& sc) {
     TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
@@ -1050,17 +1129,17 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, sc.q_keys_a, sc.q_vals_a);
     TK_LAUNCH_CHECK();
     TK_TRY(sort_pairs_u32_in(s, sc.sort_temp, sc.sort_temp_bytes, sc.q_keys_a, sc.q_keys_b, sc.q_vals_a, sc.q_order, (size_t)nq, 30));
-    int32_t* ocount = sc.counter;
-    TK_HIP(hipMemsetAsync(ocount, 0, 4, s));
+    int32_t* ocount = sc.counter;          // [0]: hand-over count, [32]: work cursor of the grouped kernel (a line of its own)
+    TK_HIP(hipMemsetAsync(ocount, 0, 33 * 4, s));
     TK_TRY(map_flush_timing(m));
     TK_HIP(hipEventRecord(m->ev_begin, s));
     const int64_t groups = (nq + 63) / 64;
     const GroupLeaves gl{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
-    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), 256 * 32);
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), group_grid_blocks(m->ctx->device));
     if (out.idx)
-        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, sc.q_order, nq, out, sc.overflow, ocount, gl);
+        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, sc.q_order, nq, out, sc.overflow, ocount, ocount + 32, gl);
     else
-        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, sc.q_order, nq, out, sc.overflow, ocount, gl);
+        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, sc.q_order, nq, out, sc.overflow, ocount, ocount + 32, gl);
     TK_LAUNCH_CHECK();
     TK_HIP(hipEventRecord(m->ev_end, s));
     m->ev_pending = true;
@@ -1285,7 +1364,7 @@ int tkhip_map_gather_static(tkhip_map* m, int64_t nq, const float* p, const floa
     sc.overflow_group = reinterpret_cast<int32_t*>(take(Q * 4));
     sc.group_leaves = reinterpret_cast<int32_t*>(take((Q / 64) * kMaxGroupLeaves * 4));
     sc.group_leaf_count = reinterpret_cast<int32_t*>(take((Q / 64) * 4));
-    sc.counter = reinterpret_cast<int32_t*>(take(256));
+    sc.counter = reinterpret_cast<int32_t*>(take(512));
     TK_REQUIRE(at < (size_t)TKHIP_STATIC_SCRATCH_BYTES, TKHIP_E_LIMIT, "tkhip_map_gather_static: scratch layout exceeds the array");
     sc.sort_temp = base + at;
     sc.sort_temp_bytes = (size_t)TKHIP_STATIC_SCRATCH_BYTES - at;
