@@ -23,9 +23,17 @@ HOST_HDRS = $(wildcard $(HOST)/*.h) include/tkhost.h include/tkhip.h
 
 all: $(LIBDIR)/libtkhip.so $(LIBDIR)/libtkhost.so $(LIBDIR)/raytracer oracle
 
-$(LIBDIR)/libtkhip.so: $(HIP_SRCS) $(HIP_HDRS)
+# one object per translation unit (under build/, git-ignored), so that a change recompiles one file
+HIP_OBJS = $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
+EXTRA_HIPFLAGS ?=
+
+build/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c -o $@ $<
+
+$(LIBDIR)/libtkhip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(HIP_OBJS)
 
 $(LIBDIR)/libtkhost.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libtkhip.so
 	@mkdir -p $(LIBDIR)
@@ -38,7 +46,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIBDIR)/*.so $(LIBDIR)/raytracer
+	rm -f $(LIBDIR)/*.so $(LIBDIR)/raytracer build/*.o
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -352,7 +352,7 @@ int tkhip_map_gather(tkhip_map* map, int64_t nq, const float* p, const float* n,
  * caller.  Work is enqueued on the map's stream; the call returns after it has
  * finished. */
 #define TKHIP_STATIC_MAX_QUERIES 65536
-#define TKHIP_STATIC_SCRATCH_BYTES (8 << 20)
+#define TKHIP_STATIC_SCRATCH_BYTES (12 << 20)
 int tkhip_map_gather_static(tkhip_map* map, int64_t nq, const float* p, const float* n, const float* wo,
                             const float* R, const float* radius2, float* flux, int32_t* found,
                             float* radius2_out, int32_t* idx);

@@ -33,8 +33,9 @@ struct GatherOut {
 // hand-over list between the two kernels, and the sort's temporary storage.
 struct GatherScratch {
     uint32_t *q_keys_a, *q_keys_b, *q_vals_a, *q_order;
+    float4* q_sorted;            // 2 x nq: q0 and q1 of the queries in the order of the curve
     int32_t *overflow, *overflow_group, *group_leaves, *group_leaf_count;
-    int32_t* counter;            // 128 ints, cleared per gather: [0] hand-over count, [32] work cursor
+    int32_t* counter;            // the hand-over count, cleared per gather
     void* sort_temp;
     size_t sort_temp_bytes;
 };
@@ -61,7 +62,7 @@ struct tkhip_map {
     tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
     int tree_mode = 0;              // 0: one sort along a Hilbert curve; 1: median splits, one sort per level
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
-    tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, overflow, counters;
+    tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, q_sorted, overflow, counters;
     tkd::DevBuf overflow_group, group_leaves, group_leaf_count;   // what the grouped kernel hands on with a query
     float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)
     int64_t last_overflow = 0;   // queries the last timed gather handed to the per-query kernel

@@ -1425,8 +1425,11 @@ int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset) {
         tkhip_map* m = s->map[which];
         TK_HIP(hipStreamSynchronize(m->stream));
         TK_TRY(map_flush_timing(m));
-        unsigned long long dev[3] = {0, 0, 0};
+        unsigned long long dev[16] = {0};
         TK_HIP(hipMemcpy(dev, m->totals.p, sizeof(dev), hipMemcpyDeviceToHost));
+        if (getenv("TKHIP_DEBUG_STAMPS"))   // section cycle sums of a profiling build of the grouped gather kernel
+            fprintf(stderr, "tkhip: map %d stamps: launches %lld wait-index %llu load %llu descent %llu steps %llu finish %llu\n", which,
+                    (long long)m->group_launches, dev[4], dev[5], dev[6], dev[7], dev[8]);
         t.launches += m->group_launches;
         t.ms_group_kernel += m->group_ms_total;
         t.queries += m->group_queries;
@@ -1436,7 +1439,7 @@ int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset) {
         t.photons_found_k[which] = (int64_t)dev[0];
         t.queries_handed_on_k[which] = (int64_t)dev[2];
         if (reset) {
-            TK_HIP(hipMemset(m->totals.p, 0, 32));
+            TK_HIP(hipMemset(m->totals.p, 0, 128));
             m->group_launches = 0; m->group_queries = 0; m->group_ms_total = 0.0;
         }
     }
