@@ -53,11 +53,13 @@ def _oracle_iteration(O, osc, param, max_depth, rr, seed, threads, height, budge
         if time.time() - t0 > budget_s and rows >= 32:
             break
     t3 = time.time()
+    tc_photon, tc_camera = r.trace_counters()
     r.close()
     scale = height / rows
     sec = (t2 - t0) + (t3 - t2) * scale
     return {"sec_iter": sec, "photon_s": t1 - t0, "build_s": t2 - t1, "camera_s": t3 - t2, "rows": rows,
-            "rays": st_p.rays + rays * scale, "gathers": gathers * scale, "spent_s": t3 - t0}
+            "rays": st_p.rays + rays * scale, "gathers": gathers * scale, "spent_s": t3 - t0,
+            "tc_photon": tc_photon, "tc_camera": tc_camera}
 
 
 def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
@@ -78,9 +80,16 @@ def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
         return (f"full photon pass {m['photon_s']:.2f}s + both KD builds {m['build_s']:.2f}s + camera pass on "
                 f"{m['rows']} of {height} rows in 8-row bands spread over the image {m['camera_s']:.2f}s "
                 f"(scaled x{height / m['rows']:.1f})")
+    # Traversal work per ray on the same rays (iteration 0), counted by the port's near-first, culled
+    # traversal of the reference's own two-level BVH: what the ray roofline below is priced with.
+    per_ray = {}
+    for name in ("tc_photon", "tc_camera"):
+        rays_, nodes_, prims_ = fair[name]
+        per_ray[name] = {"rays": rays_, "box_tests_per_ray": nodes_ / max(rays_, 1), "prim_tests_per_ray": prims_ / max(rays_, 1)}
     return {
-        "value": 1.0 / ref["sec_iter"], "unit": "iterations/s", "cores": threads, "kind": "port",
-        "sample": ("CPU oracle, iteration 0 of the same workload, reference-faithful mode (z-only KD splits, far-first "
+        "value": 1.0 / ref["sec_iter"], "unit": "iterations/s", "cores": threads, "kind": "port", "iteration": 0,
+        "per_ray": per_ray,
+        "sample": ("CPU oracle, iteration 0 of the same workload (the GPU's figure for the same iteration is iter0_ms), reference-faithful mode (z-only KD splits, far-first "
                    "BVH without t_max culling, per-call Mersenne-Twister seeding): " + describe(ref)),
         "mrays_per_s": ref["rays"] / ref["sec_iter"] / 1e6, "gathers_per_s": ref["gathers"] / ref["sec_iter"],
         "fair_mode": {"value": 1.0 / fair["sec_iter"], "unit": "iterations/s",
@@ -106,6 +115,8 @@ def main():
     ap.add_argument("--tree", choices=("curve", "median"), default="curve",
                     help="photon tree layout: one sort along a Hilbert curve (default) or median splits level by level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--jobs", type=int, default=40,
+                    help="whole renders of the scene's own iteration count timed after the steps (job_ms, iter0_ms); 0 skips them")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses N > 1 on fewer GPUs")
     args = ap.parse_args()
@@ -183,7 +194,7 @@ def main():
                          acc["overflow_global"], acc["overflow_caustic"], acc["global_paths"], acc["caustic_paths"],
                          acc["group_staged"],
                          n_inst * gt.queries, n_inst * gt.queries_handed_on_k[0], n_inst * gt.queries_handed_on_k[1],
-                         n_inst * gt.photons_found, n_inst * gt.photons_staged, n_inst * gt.launches],
+                         n_inst * gt.photons_found, n_inst * gt.photons_staged, n_inst * gt.launches, acc["rays_camera"]],
                         dtype=torch.float64, device=dev)
     times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"],
                           n_inst * gt.ms_group_kernel],
@@ -195,8 +206,34 @@ def main():
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     vals = (vals / n_inst).tolist()
     times = (times / n_inst).tolist()
-    rays, ng, nc, phot, og, oc, gpaths, cpaths, staged, t_q, t_og, t_oc, t_phot, t_staged, t_launches = vals
+    rays, ng, nc, phot, og, oc, gpaths, cpaths, staged, t_q, t_og, t_oc, t_phot, t_staged, t_launches, rays_cam = vals
     ms_group, ms_photon, ms_build, ms_camera, ms_gather, t_ms = times
+
+    # The job the reference times (src/main.cpp:51-58): a whole render of the scene's own iteration count,
+    # first iteration included, from startRaytracing to the resolved image.  Repeated so that the GPU leg of
+    # this program lasts seconds, not a fraction of one.
+    job_ms = iter0_ms = None
+    n_job_iters = backend.num_recurse
+    if world == 1 and args.jobs > 0:
+        backend.close()
+        jobs, firsts = [], []
+        for _ in range(args.jobs):
+            t_a = time.perf_counter()
+            backend = D.HipBackend(scene, param, max_depth, rr, seed, W, H, rank, world, local_rank)
+            _abi.check(backend.lib, backend.lib.tkhip_sppm_set_tree(backend.h, 1 if args.tree == "median" else 0), "tkhip_sppm_set_tree")
+            t_b = time.perf_counter()
+            backend.iteration_single(0)
+            t_c = time.perf_counter()
+            for it in range(1, n_job_iters):
+                backend.iteration_single(it)
+            backend.resolve()
+            t_d = time.perf_counter()
+            backend.close()
+            jobs.append((t_d - t_b) * 1e3)
+            firsts.append((t_c - t_b) * 1e3)
+        job_ms = float(np.median(jobs))
+        iter0_ms = float(np.median(firsts))
+        backend = None
 
     if rank == 0:
         its = args.steps / elapsed
@@ -239,6 +276,10 @@ def main():
             "photon_paths_per_s": (gpaths + cpaths) / (ms_step * 1e-3),
             "phase_ms": {"photon": ms_photon, "kd_build": ms_build, "camera": ms_camera, "gather": ms_gather,
                          "gather_group_kernel": ms_group},
+            "job_ms": job_ms, "iter0_ms": iter0_ms,
+            "job": (f"{n_job_iters} iterations (the scene's recurse) from startRaytracing to the resolved image, first iteration "
+                    f"included, median of {args.jobs} renders; value / ms_per_step are steady-state iterations {args.warmup}.."
+                    f"{args.warmup + args.steps - 1}" if job_ms is not None else None),
             "roofline": {"bound": "hbm", "kernel": "k_gather_group", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "launches": launches / world, "avg_launch_ms": avg_launch_ms,
@@ -249,12 +290,36 @@ def main():
                                    "note": "the same kernel with the GPU to itself (instrumented iterations after the "
                                            "timed region, the two maps one after the other)"}},
         }
+        # The whole gather phase (query sort, both gather kernels of both maps, the fused pixel update), from the
+        # instrumented iterations: every gather's 56 B query + 26 B per photon found + 40 B pixel slice.
+        gather_bytes = 96.0 * (ng + nc) + 26.0 * phot
+        gp = gather_bytes / (ms_gather * 1e-3) / 1e9 if ms_gather > 0 else 0.0
+        out["roofline_gather_phase"] = {"bound": "hbm", "kernels": "k_query_curve, radix sort, k_sort_queries, k_gather_group, k_gather_wave (both maps)",
+                                        "achieved": gp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gp / HBM_PEAK_GBS,
+                                        "ms": ms_gather, "algorithmic_bytes": gather_bytes,
+                                        "gathers": ng + nc, "photons_found": phot}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, param, max_depth, rr, seed, args.cpu_threads)
+            # Path kernels: B_ray = 32 B ray + 48 B hit + 32 B per box test + 48 B per primitive test, the tests
+            # per ray counted by the CPU port on the same rays (implementation independent); the camera lane's
+            # rays over the time its two kernels take, the light lanes' over theirs (the lanes run side by side).
+            pr = out["cpu_baseline"]["per_ray"]
+            def b_ray(c):
+                return 32.0 + 48.0 + 32.0 * c["box_tests_per_ray"] + 48.0 * c["prim_tests_per_ray"]
+            cam = rays_cam * b_ray(pr["tc_camera"]) / (ms_camera * 1e-3) / 1e9 if ms_camera > 0 else 0.0
+            lig = (rays - rays_cam) * b_ray(pr["tc_photon"]) / (ms_photon * 1e-3) / 1e9 if ms_photon > 0 else 0.0
+            out["roofline_paths"] = {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "camera": {"kernels": "k_camera_first, k_camera_paths", "rays": rays_cam, "bytes_per_ray": b_ray(pr["tc_camera"]),
+                           "ms": ms_camera, "achieved": cam, "frac": cam / HBM_PEAK_GBS},
+                "light": {"kernels": "k_photon_first<0,1>, k_photon_paths<0,1>", "rays": rays - rays_cam,
+                          "bytes_per_ray": b_ray(pr["tc_photon"]), "ms": ms_photon, "achieved": lig, "frac": lig / HBM_PEAK_GBS},
+                "note": "the three lanes run side by side, so each figure is that lane's rays over its own wall time"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    backend.close()
+    if backend is not None:
+        backend.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

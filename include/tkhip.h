@@ -130,6 +130,7 @@ typedef struct TkIterStats {
     float ms_gather;          /* all gather kernels incl. query sort + pixel update */
     float ms_gather_kernel;   /* the dominant (grouped) gather kernel only          */
     float ms_total;
+    int64_t rays_camera;      /* of `rays`: those of the camera paths (the rest are light paths) */
 } TkIterStats;
 
 typedef struct tkhip_ctx tkhip_ctx;

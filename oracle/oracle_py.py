@@ -60,6 +60,7 @@ def lib():
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "orc_sppm_destroy": (None, [C.c_void_p]),
         "orc_sppm_set_jitter": (None, [C.c_void_p, C.c_int]),
+        "orc_sppm_trace_counters": (None, [C.c_void_p, i64p]),
         "orc_sppm_set_tie_rule": (None, [C.c_void_p, C.c_int]),
         "orc_map_set_tie_rule": (None, [C.c_void_p, C.c_int]),
         "orc_sppm_photon_pass": (None, [C.c_void_p, C.c_int, C.POINTER(_abi.TkIterStats)]),
@@ -188,6 +189,12 @@ class OracleSppm:
 
     def set_jitter(self, on):
         lib().orc_sppm_set_jitter(self.h, 1 if on else 0)
+
+    def trace_counters(self):
+        """(rays, box tests, primitive tests) of the photon passes and of the camera passes so far."""
+        out = np.zeros(6, np.int64)
+        lib().orc_sppm_trace_counters(self.h, out.ctypes.data_as(i64p))
+        return tuple(int(v) for v in out[:3]), tuple(int(v) for v in out[3:])
 
     def set_tie_rule(self, by_index):
         lib().orc_sppm_set_tie_rule(self.h, 1 if by_index else 0)

@@ -1425,6 +1425,7 @@ struct orc_sppm {
     /* this rank's traced photons (before exchange) */
     PhotonRec* loc_g; int64_t n_loc_g; PhotonRec* loc_c; int64_t n_loc_c;
     int64_t local_shot_g, local_shot_c;     /* cumulative local path counters */
+    int64_t tc_photon[3], tc_camera[3];     /* rays, box tests, primitive tests of the passes so far */
     int64_t caustic_hoff;                   /* global paths shot before the current iteration */
     int64_t last_shot_g, last_shot_c;       /* paths of the last pass */
     int64_t shoot_g, shoot_c;               /* cumulative over all ranks */
@@ -1551,7 +1552,7 @@ static void photon_pass_kind(orc_sppm* r, int kind, TkIterStats* st) {
     int slots = kind == 0 ? r->max_depth : 1;
     double* yield = kind == 0 ? &r->yield_g : &r->yield_c;
     TraceCounters tcs[256]; memset(tcs, 0, sizeof(tcs));
-    int64_t emitted_cap = kind == 0 ? (int64_t)1 << 40 : quota * 4000 + 100000;  /* stop if nothing can be stored */
+    int64_t emitted_cap = quota * 4000 + 100000;  /* stop if nothing can be stored */
     while (stored < quota && shot < emitted_cap) {
         int64_t need = quota - stored;
         int64_t B = (int64_t)(need / *yield * 1.02) + 256;
@@ -1574,6 +1575,7 @@ static void photon_pass_kind(orc_sppm* r, int kind, TkIterStats* st) {
     if (kind == 0) { r->n_loc_g = stored; r->last_shot_g = shot; r->local_shot_g += shot; }
     else { r->n_loc_c = stored; r->last_shot_c = shot; r->local_shot_c += shot; }
     if (st) for (int t = 0; t < 256; ++t) st->rays += tcs[t].rays;
+    for (int t = 0; t < 256; ++t) { r->tc_photon[0] += tcs[t].rays; r->tc_photon[1] += tcs[t].nodes; r->tc_photon[2] += tcs[t].prims; }
 }
 
 static void install_map(orc_map* m, const PhotonRec* recs, int64_t n) {
@@ -1743,7 +1745,8 @@ void orc_sppm_camera_pass(orc_sppm* r, int iter, int y0, int y1, TkIterStats* st
     CamJob job = {r, iter, y0, cts};
     parallel_for(T, y1 - y0, 1, camera_row_job, &job);
     for (int t = 0; t < T; ++t) {
-        if (st) { st->rays += cts[t].tc.rays; st->gathers_global += cts[t].gg; st->gathers_caustic += cts[t].gc; st->gather_photons += cts[t].gphot; }
+        r->tc_camera[0] += cts[t].tc.rays; r->tc_camera[1] += cts[t].tc.nodes; r->tc_camera[2] += cts[t].tc.prims;
+        if (st) { st->rays += cts[t].tc.rays; st->rays_camera += cts[t].tc.rays; st->gathers_global += cts[t].gg; st->gathers_caustic += cts[t].gc; st->gather_photons += cts[t].gphot; }
         free(cts[t].d2); free(cts[t].nb);
     }
     free(cts);
@@ -1783,6 +1786,10 @@ orc_sppm* orc_sppm_begin(orc_scene* s, const TkSppmParam* param, int max_depth, 
     return r;
 }
 /* jitter = 0: the camera sampler is the reference's StratifiedSampler built with jitter = false. */
+/* rays, box tests and primitive tests of all photon passes (out[0..2]) and camera passes (out[3..5]) so far */
+void orc_sppm_trace_counters(orc_sppm* r, int64_t out[6]) {
+    for (int i = 0; i < 3; ++i) { out[i] = r->tc_photon[i]; out[3 + i] = r->tc_camera[i]; }
+}
 void orc_sppm_set_jitter(orc_sppm* r, int jitter) { r->no_jitter = jitter ? 0 : 1; }
 void orc_sppm_set_tie_rule(orc_sppm* r, int by_index) { r->gmap->tie_by_index = by_index; r->cmap->tie_by_index = by_index; }
 void orc_sppm_destroy(orc_sppm* r) {

@@ -94,6 +94,10 @@ orc_sppm* orc_sppm_begin(orc_scene* s, const TkSppmParam* param, int max_depth, 
 void orc_sppm_destroy(orc_sppm* r);
 /* jitter 0: stratum centres, as StratifiedSampler(x, y, jitter = false) (src/core/sampler.cpp:51, :61-62). */
 void orc_sppm_set_jitter(orc_sppm* r, int jitter);
+/* Traversal work of the passes so far: rays, box tests, primitive tests of the photon passes
+ * (out[0..2]) and of the camera passes (out[3..5]); src/BVH.cpp:245-288 counts one box test per
+ * node popped and one primitive test per Object::intersect of a leaf. */
+void orc_sppm_trace_counters(orc_sppm* r, int64_t out[6]);
 void orc_sppm_set_tie_rule(orc_sppm* r, int by_index);   /* orc_map_set_tie_rule for both maps */
 void orc_sppm_photon_pass(orc_sppm* r, int iter, TkIterStats* st);
 void orc_sppm_build_maps(orc_sppm* r, TkIterStats* st);

@@ -61,7 +61,8 @@ class TkIterStats(C.Structure):
                 ("gather_photons", C.c_int64), ("overflow_global", C.c_int64), ("overflow_caustic", C.c_int64),
                 ("group_staged", C.c_int64),
                 ("ms_photon", C.c_float), ("ms_build", C.c_float), ("ms_camera", C.c_float),
-                ("ms_gather", C.c_float), ("ms_gather_kernel", C.c_float), ("ms_total", C.c_float)]
+                ("ms_gather", C.c_float), ("ms_gather_kernel", C.c_float), ("ms_total", C.c_float),
+                ("rays_camera", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

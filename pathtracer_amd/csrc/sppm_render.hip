@@ -1059,6 +1059,7 @@ static int collect_rays(tkhip_ctx* ctx, int lane, TkIterStats* st) {
     int64_t rays = 0;
     TK_TRY(read_u64_counter(ctx->sppm->lane[lane], C_RAYS, &rays));
     st->rays += rays;
+    if (lane == 2) st->rays_camera += rays;
     return TKHIP_OK;
 }
 
