@@ -291,6 +291,23 @@ int tkhip_sppm_import_planes(tkhip_ctx* ctx, const float* device_src);
  * iterations = the divisor of Ld (numRecurse in the reference). */
 int tkhip_sppm_resolve_rgb8(tkhip_ctx* ctx, int iterations, uint8_t* host_out);
 
+/* Progressive display (SppmTracer::rendering, src/tracer/TkSppmTracer.cpp:43-102,
+ * the frame buffer RayTracer::updateScreen hands to glDrawPixels,
+ * src/core/TkRayTracer.cpp:54-73).  The frame buffer lives on the device: one
+ * RGBA8 word per pixel (red in the low byte, alpha 255), in the order of the
+ * SPPMPixel array (row y of the raster, no flip), tone-mapped as the final image
+ * with Ld divided by the rounded-up iteration count.
+ * tkhip_sppm_set_preview(every_n): from now on tkhip_sppm_iteration /
+ * tkhip_sppm_camera_pass refresh it after every every_n-th iteration (0: never),
+ * enqueued behind the pass and not waited for: no host round trip per step.
+ * tkhip_sppm_preview: waits for a pending refresh (refresh != 0: makes one now)
+ * and returns the device pointer (valid until the render ends) and the last
+ * iteration it shows (-1: none yet).  tkhip_sppm_read_preview copies it to
+ * host memory (width*height words), e.g. to save an image mid-render. */
+int tkhip_sppm_set_preview(tkhip_ctx* ctx, int every_n);
+int tkhip_sppm_preview(tkhip_ctx* ctx, int refresh, const uint32_t** device_rgba, int* iteration);
+int tkhip_sppm_read_preview(tkhip_ctx* ctx, uint32_t* host_rgba, int* iteration);
+
 /* Cumulative shoot counters and the rounded-up iteration count. */
 int tkhip_sppm_counters(tkhip_ctx* ctx, int64_t* shoot_global, int64_t* shoot_caustic,
                         int32_t* num_recurse);

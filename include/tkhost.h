@@ -69,6 +69,16 @@ void tkhost_camera_matrices(const TkCameraConfig* cam, int width, int height, fl
 int tkhost_render(tkhost_scene* s, int device, int width, int height, const char* out_ppm,
                   uint64_t seed, double* seconds_out);
 
+/* The windowed flow without a window (src/TkRenderer.cpp:186-222 driving
+ * RayTracer::updateScreen, src/core/TkRayTracer.cpp:54-73): startRaytracing(),
+ * one updateScreen() per frame, the frame buffer refreshed on the device after
+ * every iteration.  After save_after steps (0 <= save_after < iterations) the
+ * image is saved mid-render to mid_ppm (may be null) and the RGBA8 frame buffer
+ * copied to frame_rgba (width*height words, may be null); the final image goes
+ * to out_ppm. */
+int tkhost_render_windowed(tkhost_scene* s, int device, int width, int height, const char* out_ppm,
+                           uint64_t seed, int save_after, const char* mid_ppm, uint32_t* frame_rgba);
+
 /* Writes a binary P6 PPM (src/tracer/TkSppmTracer.cpp:530-535). */
 int tkhost_write_ppm(const char* path, int width, int height, const uint8_t* rgb);
 

@@ -112,6 +112,9 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_export_planes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tkhip_sppm_import_planes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tkhip_sppm_resolve_rgb8": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p]),
+    "tkhip_sppm_set_preview": (C.c_int, [C.c_void_p, C.c_int]),
+    "tkhip_sppm_preview": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_int32_p]),
+    "tkhip_sppm_read_preview": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
     "tkhip_sppm_counters": (C.c_int, [C.c_void_p, c_int64_p, c_int64_p, c_int32_p]),
     "tkhip_map_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "tkhip_map_destroy": (None, [C.c_void_p]),
@@ -160,6 +163,8 @@ TKHOST_SYMBOLS = {
     "tkhost_camera_matrices": (None, [C.POINTER(TkCameraConfig), C.c_int, C.c_int, c_float_p, c_float_p]),
     "tkhost_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64,
                                 C.POINTER(C.c_double)]),
+    "tkhost_render_windowed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_int,
+                                         C.c_char_p, C.c_void_p]),
     "tkhost_write_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_uint8_p]),
 }
 

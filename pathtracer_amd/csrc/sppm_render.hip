@@ -142,6 +142,8 @@ struct SppmState {
     int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
     DevBuf qbuf[2];
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
+    DevBuf preview;                  // RGBA8 frame buffer on the device (tkhip_sppm_set_preview)
+    int preview_every = 0, preview_iter = -1;
 };
 
 // Paths that outlive the first stage of a pass wait here for the second one,
@@ -711,6 +713,26 @@ __global__ void k_resolve(const float* planes, int64_t np, int W, int H, int num
     }
 }
 
+// The tone-mapped frame buffer of the windowed path (SppmTracer::rendering,
+// src/tracer/TkSppmTracer.cpp:85-97): one RGBA8 word per pixel, red in the low byte, alpha 255, in
+// the order of the SPPMPixel array (no row flip: glDrawPixels draws bottom-up).
+__global__ void k_preview(const float* planes, int64_t np, int num_recurse, float shoot_g, float shoot_c,
+                          int caustic_stored, uint32_t* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    float cr2 = planes[11 * np + i], gr2 = planes[12 * np + i];
+    uint32_t v = 0xFF000000u;
+    for (int ch = 0; ch < 3; ++ch) {
+        float c = planes[ch * np + i] / (float)num_recurse;
+        if (caustic_stored > 0) c = c + planes[(3 + ch) * np + i] / (kPi * cr2 * shoot_c);
+        else c = c + 0.f;
+        c = c + planes[(6 + ch) * np + i] / (kPi * gr2 * shoot_g);
+        float cl = sse_max(sse_min(c, 1.0f), 0.0f);
+        v |= (uint32_t)(255 * powf(cl, 0.6f)) << (8 * ch);
+    }
+    out[i] = v;
+}
+
 __global__ void k_init_planes(float* planes, int64_t np, float radius2) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= np) return;
@@ -742,6 +764,7 @@ void destroy_sppm(tkhip_ctx* ctx) {
     }
     s->planes.release();
     s->rows.release();
+    s->preview.release();
     if (s->lane[0].stream) {
         hipStream_t three[3] = {s->lane[0].stream, s->lane[1].stream, s->lane[2].stream};
         for (hipStream_t st : three) (void)hipStreamSynchronize(st);
@@ -1063,6 +1086,20 @@ static int collect_rays(tkhip_ctx* ctx, int lane, TkIterStats* st) {
     return TKHIP_OK;
 }
 
+// After the camera pass of iteration `iter`: refreshes the device-resident preview when one is due.
+// Enqueued on the context's stream, not waited for.
+static int maybe_preview(tkhip_ctx* ctx, int iter, bool force) {
+    SppmState* s = ctx->sppm;
+    if (!s->preview.p) return TKHIP_OK;
+    if (!force && (s->preview_every <= 0 || (iter + 1) % s->preview_every != 0)) return TKHIP_OK;
+    k_preview<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, s->num_recurse,
+                                                               (float)s->shoot[0], (float)s->shoot[1], (int)s->stored_c,
+                                                               s->preview.as<uint32_t>());
+    TK_LAUNCH_CHECK();
+    s->preview_iter = iter;
+    return TKHIP_OK;
+}
+
 static void fill_photon_stats(SppmState* s, TkIterStats* st) {
     st->global_paths = s->last_shot[0]; st->caustic_paths = s->last_shot[1];
     st->global_stored = s->n_loc[0]; st->caustic_stored = s->n_loc[1];
@@ -1333,7 +1370,7 @@ int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     if (st) st->ms_camera += (float)(now_ms() - t0);
     TK_TRY(gather_both(ctx, st));
     TK_TRY(collect_rays(ctx, 2, st));
-    return TKHIP_OK;
+    return maybe_preview(ctx, iter, false);
 }
 
 // One iteration on a single GPU.  The camera paths do not read the photon
@@ -1415,6 +1452,43 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         st->ms_total += (float)(now_ms() - t0);
         fill_photon_stats(s, st);
     }
+    return maybe_preview(ctx, iter, false);
+}
+
+int tkhip_sppm_set_preview(tkhip_ctx* ctx, int every_n) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_set_preview");
+    TK_REQUIRE(every_n >= 0, TKHIP_E_ARG, "tkhip_sppm_set_preview: interval must be >= 0");
+    SppmState* s = ctx->sppm;
+    s->preview_every = every_n;
+    if (every_n > 0 && !s->preview.p) {
+        TK_TRY(s->preview.ensure((size_t)s->n_pixels * 4));
+        TK_HIP(hipMemsetAsync(s->preview.p, 0, (size_t)s->n_pixels * 4, ctx->stream));
+        s->preview_iter = -1;
+    }
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_preview(tkhip_ctx* ctx, int refresh, const uint32_t** device_rgba, int* iteration) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_preview");
+    SppmState* s = ctx->sppm;
+    if (!s->preview.p) {
+        TK_TRY(s->preview.ensure((size_t)s->n_pixels * 4));
+        TK_HIP(hipMemsetAsync(s->preview.p, 0, (size_t)s->n_pixels * 4, ctx->stream));
+        s->preview_iter = -1;
+    }
+    if (refresh) TK_TRY(maybe_preview(ctx, s->preview_iter < 0 ? 0 : s->preview_iter, true));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    if (device_rgba) *device_rgba = s->preview.as<uint32_t>();
+    if (iteration) *iteration = s->preview_iter;
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_read_preview(tkhip_ctx* ctx, uint32_t* host_rgba, int* iteration) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_read_preview");
+    TK_REQUIRE(host_rgba, TKHIP_E_ARG, "tkhip_sppm_read_preview: null buffer");
+    const uint32_t* dev = nullptr;
+    TK_TRY(tkhip_sppm_preview(ctx, 0, &dev, iteration));
+    TK_HIP(hipMemcpy(host_rgba, dev, (size_t)ctx->sppm->n_pixels * 4, hipMemcpyDeviceToHost));
     return TKHIP_OK;
 }
 

@@ -64,7 +64,8 @@ public:
     virtual void render(std::string filename) = 0;
     bool done() const { return mState == DONE; }
     const std::string& error() const { return mError; }
-    const uint32_t* frameBuffer() const { return mFrameBuffer.data(); }
+    // RGBA8, rows in raster order (the buffer updateScreen hands to glDrawPixels in the reference)
+    virtual const uint32_t* frameBuffer() { return mFrameBuffer.data(); }
 };
 
 class SppmTracer : public RayTracer {
@@ -73,6 +74,7 @@ protected:
     int numRecurse = 0;
     int curRecurse = 0;
     std::vector<TkIterStats> mStats;
+    bool mPreviewStale = false;           // the device frame buffer is newer than mFrameBuffer
     void rendering() override;
     bool resolve(std::vector<uint8_t>* rgb);
 public:
@@ -80,6 +82,10 @@ public:
     void startRaytracing() override;
     void saveImage(std::string filename = "") override;
     void render(std::string filename) override;
+    const uint32_t* frameBuffer() override;
+    // Progressive display: the device-resident frame buffer is refreshed after every n-th step of
+    // updateScreen() / rendering() (call after startRaytracing; the windowed path uses 1).
+    bool setPreviewInterval(int n) { return mCtx && tkhip_sppm_set_preview(mCtx, n) == 0; }
     const std::vector<TkIterStats>& stats() const { return mStats; }
 };
 

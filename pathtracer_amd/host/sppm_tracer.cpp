@@ -121,6 +121,12 @@ void SppmTracer::startRaytracing() {
         return;
     }
     fprintf(stderr, "\r[Tracer] device %d, %dx%d, %d iterations\n", mDevice, mWidth, mHeight, numRecurse);
+    // The windowed path shows every iteration; the frame buffer is refreshed on the device.
+    if (tkhip_sppm_set_preview(mCtx, 1) != 0) {
+        fail("tkhip_sppm_set_preview");
+        return;
+    }
+    mPreviewStale = false;
     RayTracer::startRaytracing();
 }
 
@@ -148,26 +154,45 @@ void SppmTracer::rendering() {
     fprintf(stderr, "\r[Tracer] Iteration %d... 100%%  (%.2f ms: photons %.2f, build %.2f, camera %.2f, gather %.2f)\n",
             curRecurse, st.ms_total, st.ms_photon, st.ms_build, st.ms_camera, st.ms_gather);
     ++curRecurse;
-    std::vector<uint8_t> rgb;
-    if (resolve(&rgb)) {
-        // preview buffer: RGBA, same row order as the SPPMPixel array (y down)
-        for (int y = 0; y < mHeight; ++y)
-            for (int x = 0; x < mWidth; ++x) {
-                const uint8_t* p = &rgb[(size_t(mHeight - 1 - y) * mWidth + x) * 3];
-                mFrameBuffer[size_t(y) * mWidth + x] = 0xFF000000u | (uint32_t(p[2]) << 16) | (uint32_t(p[1]) << 8) | p[0];
-            }
-    }
+    // The tone-mapped frame buffer stays on the device (the library refreshed it behind the pass);
+    // the host copy is fetched when somebody asks for it (frameBuffer(), saveImage).
+    mPreviewStale = true;
     if (curRecurse >= numRecurse) {
         fprintf(stderr, "\r[Tracer] Rendering Done!\n");
         mState = DONE;
     }
 }
 
+const uint32_t* SppmTracer::frameBuffer() {
+    if (mPreviewStale && mCtx) {
+        int shown = -1;
+        if (tkhip_sppm_read_preview(mCtx, mFrameBuffer.data(), &shown) != 0) fail("tkhip_sppm_read_preview");
+        mPreviewStale = false;
+    }
+    return mFrameBuffer.data();
+}
+
+// Mid-render (key 's' of the windowed path, src/TkRenderer.cpp:220-222) the image is the current frame
+// buffer, rows flipped as the final PPM has them; after the last iteration it is the resolved image.
 void SppmTracer::saveImage(std::string filename) {
     if (mState != DONE && mState != RENDERING) return;
     if (filename.empty()) filename = "binary.ppm";
     std::vector<uint8_t> rgb;
-    if (!resolve(&rgb)) return;
+    if (mState == RENDERING) {
+        int shown = -1;
+        std::vector<uint32_t> fb(size_t(mWidth) * size_t(mHeight));
+        if (tkhip_sppm_preview(mCtx, 1, nullptr, nullptr) != 0 || tkhip_sppm_read_preview(mCtx, fb.data(), &shown) != 0) {
+            fail("tkhip_sppm_read_preview");
+            return;
+        }
+        rgb.resize(fb.size() * 3);
+        for (int y = 0; y < mHeight; ++y)
+            for (int x = 0; x < mWidth; ++x) {
+                const uint32_t v = fb[size_t(y) * mWidth + x];
+                uint8_t* p = &rgb[(size_t(mHeight - 1 - y) * mWidth + x) * 3];
+                p[0] = uint8_t(v); p[1] = uint8_t(v >> 8); p[2] = uint8_t(v >> 16);
+            }
+    } else if (!resolve(&rgb)) return;
     fprintf(stderr, "\n[Tracer] Saving to file: %s... ", filename.c_str());
     if (tkhost_write_ppm(filename.c_str(), mWidth, mHeight, rgb.data()) == 0) fprintf(stderr, "Done!\n");
     else fprintf(stderr, "FAILED\n");
@@ -184,6 +209,7 @@ void SppmTracer::render(std::string filename) {
     if (want_stats && atoi(want_stats) != 0) {
         while (mState == RENDERING) rendering();
     } else {
+        if (mState == RENDERING && tkhip_sppm_set_preview(mCtx, 0) != 0) fail("tkhip_sppm_set_preview");
         int64_t shot[2] = {0, 0};
         while (mState == RENDERING) {
             if (tkhip_sppm_iteration(mCtx, curRecurse, nullptr) != 0) {
@@ -244,5 +270,44 @@ extern "C" int tkhost_render(tkhost_scene* s, int device, int width, int height,
         tk::setHostError(tracer->error().empty() ? "render did not finish" : tracer->error());
         return -1;
     }
+    return 0;
+}
+
+// The windowed flow without a window (src/TkRenderer.cpp:186-222): startRaytracing(), then one
+// updateScreen() per frame; after `save_after` steps the 's' key, i.e. saveImage(mid_ppm), and at
+// the end the final image.  frame_rgba (width*height words, may be null) receives the frame buffer
+// as it stood when the mid-render image was saved.
+extern "C" int tkhost_render_windowed(tkhost_scene* s, int device, int width, int height, const char* out_ppm,
+                                      uint64_t seed, int save_after, const char* mid_ppm, uint32_t* frame_rgba) {
+    if (!s) {
+        tk::setHostError("tkhost_render_windowed: null scene");
+        return -1;
+    }
+    tk::Config& cfg = s->config;
+    int w = width > 0 ? width : cfg.width, h = height > 0 ? height : cfg.height;
+    std::string err;
+    std::unique_ptr<tk::RayTracer> tracer = tk::createTracer(cfg.tracer, &err);
+    if (!tracer) {
+        tk::setHostError(err);
+        return -1;
+    }
+    tk::Camera camera(cfg.camera, w, h);
+    tracer->setDevice(device);
+    tracer->setSeed(seed);
+    tracer->setScene(&cfg.scene);
+    tracer->setCamera(&camera);
+    tracer->startRaytracing();
+    for (int step = 0; !tracer->done() && tracer->error().empty(); ++step) {
+        if (step == save_after) {
+            if (mid_ppm) tracer->saveImage(mid_ppm);
+            if (frame_rgba) memcpy(frame_rgba, tracer->frameBuffer(), size_t(w) * size_t(h) * 4);
+        }
+        tracer->updateScreen();
+    }
+    if (!tracer->done()) {
+        tk::setHostError(tracer->error().empty() ? "render did not finish" : tracer->error());
+        return -1;
+    }
+    tracer->saveImage(out_ppm ? out_ppm : cfg.outfilename);
     return 0;
 }

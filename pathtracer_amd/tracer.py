@@ -322,6 +322,20 @@ class SppmTracer:
               "tkhip_sppm_resolve_rgb8")
         return out
 
+    def set_preview(self, every_n):
+        """Device-resident RGBA8 frame buffer refreshed after every every_n-th iteration (0: never)."""
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_set_preview(self.ctx.h, every_n), "tkhip_sppm_set_preview")
+
+    def preview(self, refresh=False):
+        """(frame buffer as (H, W, 4) uint8 RGBA in SPPMPixel row order, iteration it shows)."""
+        buf = np.empty((self.height, self.width), np.uint32)
+        it = C.c_int32(-1)
+        if refresh:
+            check(self.ctx.lib, self.ctx.lib.tkhip_sppm_preview(self.ctx.h, 1, None, None), "tkhip_sppm_preview")
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_read_preview(self.ctx.h, buf.ctypes.data, C.byref(it)),
+              "tkhip_sppm_read_preview")
+        return buf.view(np.uint8).reshape(self.height, self.width, 4), it.value
+
     def saveImage(self, filename, img=None):
         img = self.resolve() if img is None else img
         with open(filename, "wb") as f:
