@@ -163,6 +163,18 @@ int tkhip_set_scene(tkhip_ctx* ctx,
                     const TkMaterial* materials, int n_materials,
                     const TkLight* lights, int n_lights);
 
+/* Who builds the scene hierarchy (buildBVH, src/BVH.cpp:62-243, called per
+ * mesh from src/Triangle.cpp:103-180 and for the scene from
+ * src/core/Scene.cpp:18-20): 0 (default) the GPU for scenes of 4096 primitives
+ * or more and host threads below, 1 host threads (binned SAH), 2 the GPU
+ * (Morton order, SAH over sixteen cuts of each run).  Takes effect at the next
+ * tkhip_set_scene.  The closest hit of a ray does not depend on the choice.
+ * tkhip_bvh_info reports the tree of the current scene and the wall time of its
+ * construction (any pointer may be null). */
+int tkhip_set_bvh_builder(tkhip_ctx* ctx, int mode);
+int tkhip_bvh_info(tkhip_ctx* ctx, int32_t* n_nodes, int32_t* depth, int32_t* built_on_device,
+                   float* build_ms);
+
 /* Row-major 4x4 matrices as the reference stores them (src/Matrix4.h:11-15):
  * c2w = CameraInfo::c2w after rotate(0,0)+setTranslation (src/main.cpp:39-40),
  * raster2cam = Camera::rasterToCamera (src/core/camera.cpp:15-20).

@@ -112,6 +112,8 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_export_planes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tkhip_sppm_import_planes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tkhip_sppm_resolve_rgb8": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p]),
+    "tkhip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int]),
+    "tkhip_bvh_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_float_p]),
     "tkhip_sppm_set_preview": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_preview": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_int32_p]),
     "tkhip_sppm_read_preview": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),

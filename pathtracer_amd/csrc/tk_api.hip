@@ -121,6 +121,22 @@ void tkhip_destroy(tkhip_ctx* ctx) {
     delete ctx;
 }
 
+int tkhip_set_bvh_builder(tkhip_ctx* ctx, int mode) {
+    TK_REQUIRE(ctx, TKHIP_E_ARG, "tkhip_set_bvh_builder: null context");
+    TK_REQUIRE(mode >= 0 && mode <= 2, TKHIP_E_ARG, "tkhip_set_bvh_builder: mode %d (0 by size, 1 host, 2 device)", mode);
+    ctx->bvh_builder = mode;
+    return TKHIP_OK;
+}
+
+int tkhip_bvh_info(tkhip_ctx* ctx, int32_t* n_nodes, int32_t* depth, int32_t* built_on_device, float* build_ms) {
+    TK_REQUIRE(ctx && ctx->has_scene, TKHIP_E_STATE, "tkhip_bvh_info: no scene");
+    if (n_nodes) *n_nodes = ctx->scene.n_nodes;
+    if (depth) *depth = ctx->bvh_depth;
+    if (built_on_device) *built_on_device = ctx->bvh_on_device;
+    if (build_ms) *build_ms = ctx->bvh_ms;
+    return TKHIP_OK;
+}
+
 int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, const TkTriangle* tris, int n_tris,
                     const TkSphere* spheres, int n_spheres, const TkMaterial* materials, int n_materials,
                     const TkLight* lights, int n_lights) {
@@ -162,28 +178,55 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
             fprintf(stderr, "[tkhip] set_scene: %s at %.1f ms\n", what,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
     };
-    HostBvh bvh;
-    build_bvh(tris, n_tris, spheres, n_spheres, kMaxLeaf, kStackDepth, &bvh);
-    lap("tree built");
-    TK_REQUIRE(bvh.max_depth < kStackDepth - 1, TKHIP_E_LIMIT, "scene BVH depth %d exceeds the traversal stack", bvh.max_depth);
-
     const size_t nprim = (size_t)n_tris + n_spheres;
-    std::vector<TriIsect> isect(nprim);
-    host_parallel_for(nprim, [&](size_t begin, size_t end) {
-        for (size_t s = begin; s < end; ++s) {
-            int id = bvh.order[s];
-            TriIsect& t = isect[s];
-            memset(&t, 0, sizeof(t));
-            t.prim = id;
-            if (id < n_tris) {
-                for (int a = 0; a < 3; ++a) {
-                    t.v0[a] = tris[id].v0[a];
-                    t.e1[a] = tris[id].v1[a] - tris[id].v0[a];   // src/Triangle.hpp:21-22
-                    t.e2[a] = tris[id].v2[a] - tris[id].v0[a];
+    hipStream_t s = ctx->stream;
+    const bool on_device = nprim >= 3 && (ctx->bvh_builder == 2 || (ctx->bvh_builder == 0 && nprim >= (size_t)kDeviceBuildMin));
+    int n_nodes = 0, depth = 0;
+    float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    if (on_device) {
+        DevBuf d_tris, d_sph;
+        struct Cleanup {
+            DevBuf *a, *b;
+            ~Cleanup() { a->release(); b->release(); }
+        } cleanup{&d_tris, &d_sph};
+        TK_TRY(d_tris.ensure(std::max<size_t>((size_t)n_tris, 1) * sizeof(TkTriangle)));
+        TK_TRY(d_sph.ensure(std::max<size_t>((size_t)n_spheres, 1) * sizeof(TkSphere)));
+        if (n_tris) TK_HIP(hipMemcpyAsync(d_tris.p, tris, (size_t)n_tris * sizeof(TkTriangle), hipMemcpyHostToDevice, s));
+        if (n_spheres) TK_HIP(hipMemcpyAsync(d_sph.p, spheres, (size_t)n_spheres * sizeof(TkSphere), hipMemcpyHostToDevice, s));
+        TK_TRY(build_bvh_device(s, ctx->prim_temp, d_tris.as<TkTriangle>(), n_tris, d_sph.as<TkSphere>(), n_spheres, kMaxLeaf,
+                                kStackDepth, ctx->b_nodes, ctx->b_tri_isect, &n_nodes, &depth, bmin, bmax));
+        lap("tree built on the device");
+    } else {
+        HostBvh bvh;
+        build_bvh(tris, n_tris, spheres, n_spheres, kMaxLeaf, kStackDepth, &bvh);
+        lap("tree built");
+        TK_REQUIRE(bvh.max_depth < kStackDepth - 1, TKHIP_E_LIMIT, "scene BVH depth %d exceeds the traversal stack", bvh.max_depth);
+        std::vector<TriIsect> isect(nprim);
+        host_parallel_for(nprim, [&](size_t begin, size_t end) {
+            for (size_t s = begin; s < end; ++s) {
+                int id = bvh.order[s];
+                TriIsect& t = isect[s];
+                memset(&t, 0, sizeof(t));
+                t.prim = id;
+                if (id < n_tris) {
+                    for (int a = 0; a < 3; ++a) {
+                        t.v0[a] = tris[id].v0[a];
+                        t.e1[a] = tris[id].v1[a] - tris[id].v0[a];   // src/Triangle.hpp:21-22
+                        t.e2[a] = tris[id].v2[a] - tris[id].v0[a];
+                    }
                 }
             }
-        }
-    });
+        });
+        TK_TRY(upload(ctx->b_nodes, bvh.nodes, s));
+        TK_TRY(upload(ctx->b_tri_isect, isect, s));
+        TK_HIP(hipStreamSynchronize(s));   // the vectors go out of scope
+        n_nodes = (int)bvh.nodes.size();
+        depth = bvh.max_depth;
+        for (int a = 0; a < 3; ++a) { bmin[a] = bvh.bmin[a]; bmax[a] = bvh.bmax[a]; }
+    }
+    ctx->bvh_on_device = on_device ? 1 : 0;
+    ctx->bvh_depth = depth;
+    ctx->bvh_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
     std::vector<TriShade> shade((size_t)std::max(n_tris, 1));
     std::vector<float> area((size_t)std::max(n_tris, 1), 0.f);
     host_parallel_for((size_t)n_tris, [&](size_t begin, size_t end) {
@@ -237,9 +280,6 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     std::vector<TkMaterial> mats(materials, materials + n_materials);
     ctx->h_mats = mats;
     lap("arrays laid out");
-    hipStream_t s = ctx->stream;
-    TK_TRY(upload(ctx->b_nodes, bvh.nodes, s));
-    TK_TRY(upload(ctx->b_tri_isect, isect, s));
     TK_TRY(upload(ctx->b_tri_shade, shade, s));
     TK_TRY(upload(ctx->b_spheres, sph, s));
     TK_TRY(upload(ctx->b_prim_mat, prim_mat, s));
@@ -258,8 +298,8 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     sc.lights = ctx->b_lights.as<DLight>();
     sc.light_cdf = ctx->b_cdf.as<float>();
     sc.n_tris = n_tris; sc.n_spheres = n_spheres; sc.n_lights = n_lights;
-    sc.n_nodes = (int32_t)bvh.nodes.size();
-    for (int a = 0; a < 3; ++a) { sc.bmin[a] = bvh.bmin[a]; sc.bmax[a] = bvh.bmax[a]; }
+    sc.n_nodes = n_nodes;
+    for (int a = 0; a < 3; ++a) { sc.bmin[a] = bmin[a]; sc.bmax[a] = bmax[a]; }
     ctx->has_scene = true;
     return TKHIP_OK;
 }

@@ -15,6 +15,7 @@ namespace tkd {
 
 constexpr int kStackDepth = 32;      // per-lane entries; the builder bounds the tree depth
 constexpr int kMaxLeaf = 2;          // primitives per BVH leaf
+constexpr int kDeviceBuildMin = 4096; // scenes from this many primitives on are built on the GPU by default
 constexpr int kTraceBlock = 256;     // threads per block of every kernel that traces
 
 // LDS stack: entry e of thread t lives at stack[e * STRIDE + t] (STRIDE = block

@@ -142,6 +142,12 @@ struct HostBvh {
 void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int n_spheres,
                int max_leaf, int max_stack_depth, HostBvh* out);
 
+// The same kind of tree built on the GPU from device arrays (bvh_build_device.hip): nodes and the
+// per-slot triangle records are left in `nodes` / `isect`.
+int build_bvh_device(hipStream_t stream, DevBuf& prim_temp, const TkTriangle* d_tris, int n_tris, const TkSphere* d_spheres,
+                     int n_spheres, int max_leaf, int max_stack_depth, DevBuf& nodes, DevBuf& isect, int* n_nodes, int* depth,
+                     float bmin[3], float bmax[3]);
+
 // fn(begin, end) over [0, n) in contiguous pieces on up to 16 host threads; small n runs on the caller.
 template <class F>
 void host_parallel_for(size_t n, F fn) {
@@ -174,6 +180,9 @@ struct tkhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool has_scene = false, has_camera = false;
+    int bvh_builder = 0;            // 0: by scene size, 1: host threads, 2: GPU (tkhip_set_bvh_builder)
+    int bvh_on_device = 0, bvh_depth = 0;
+    float bvh_ms = 0.f;             // wall time of the last build, uploads of its inputs included
     tkd::DScene scene{};
     tkd::DCamera cam{};
     tkd::DevBuf b_nodes, b_tri_isect, b_tri_shade, b_spheres, b_prim_mat, b_mats, b_lights, b_cdf;

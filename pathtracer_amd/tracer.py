@@ -52,6 +52,15 @@ class Context:
         except Exception:
             pass
 
+    def set_bvh_builder(self, mode):
+        """0: GPU from 4096 primitives on, host threads below; 1: host threads; 2: GPU.  Before set_scene."""
+        check(self.lib, self.lib.tkhip_set_bvh_builder(self.h, mode), "tkhip_set_bvh_builder")
+
+    def bvh_info(self):
+        n, d, dev, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+        check(self.lib, self.lib.tkhip_bvh_info(self.h, C.byref(n), C.byref(d), C.byref(dev), C.byref(ms)), "tkhip_bvh_info")
+        return {"nodes": n.value, "depth": d.value, "on_device": bool(dev.value), "ms": ms.value}
+
     def set_scene(self, scene):
         check(self.lib, self.lib.tkhip_set_scene(self.h, scene.objects, scene.n_objects, scene.triangles,
                                                  scene.n_triangles, scene.spheres, scene.n_spheres,
@@ -225,6 +234,7 @@ class SppmTracer:
         self.num_recurse = 0
         self.stats = []
         self.state = "INIT"
+        self.bvh_builder = 0   # Context.set_bvh_builder mode used by startRaytracing
 
     @classmethod
     def from_scene(cls, scene, **kw):
@@ -251,6 +261,7 @@ class SppmTracer:
         if self.ctx:
             self.ctx.close()
         self.ctx = Context(self.device)
+        self.ctx.set_bvh_builder(self.bvh_builder)
         self.ctx.set_scene(self.scene)
         self.ctx.set_camera(self.scene, self.width, self.height)
         lib = self.ctx.lib
