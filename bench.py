@@ -171,8 +171,11 @@ def main():
     sync()
     gather_totals(True)   # the grouped gather kernel is event-timed on its stream at every launch: count from here
     t0 = time.perf_counter()
+    last = args.warmup + args.steps - 1
     for it in range(args.warmup, args.warmup + args.steps):
-        D.iteration(backend, it, world)
+        # several ranks: the light paths of the next step are enqueued under this step's gathers, as a render
+        # does between its iterations (not after the last one: nothing of step K+1 is left in flight)
+        D.iteration(backend, it, world, begin_next=world > 1 and it < last)
     sync()
     elapsed = time.perf_counter() - t0
     gt = gather_totals(True)

@@ -148,6 +148,8 @@ const char* tkhip_version(void);
  * it.  Replaces the tracer object construction in parse_tracer,
  * src/TkLoader.cpp:228-251. */
 int tkhip_create(int device, tkhip_ctx** out);
+/* GPUs this process can see (0 when there is none or the runtime fails). */
+int tkhip_device_count(void);
 void tkhip_destroy(tkhip_ctx* ctx);
 
 /* --------------------------------------------------------- scene and camera */
@@ -319,6 +321,40 @@ int tkhip_sppm_resolve_rgb8(tkhip_ctx* ctx, int iterations, uint8_t* host_out);
 int tkhip_sppm_set_preview(tkhip_ctx* ctx, int every_n);
 int tkhip_sppm_preview(tkhip_ctx* ctx, int refresh, const uint32_t** device_rgba, int* iteration);
 int tkhip_sppm_read_preview(tkhip_ctx* ctx, uint32_t* host_rgba, int* iteration);
+
+/* ------------------------------------------------ several GPUs, one process
+ * The reference spreads an iteration over the threads of one machine (TkSpawn /
+ * TkWait, src/Threads.cpp:19-56, called from src/tracer/TkSppmTracer.cpp:411-438
+ * and :456-496); a group spreads it over the GPUs of one process instead: one
+ * context and one host thread per GPU, work split as tkhip_sppm_begin(rank,
+ * world) describes, the photons of the other ranks pulled with direct peer
+ * copies between the two barriers of an iteration.  devices may name a GPU more
+ * than once (a rehearsal of the multi-GPU path on fewer GPUs).
+ * set_scene / set_camera / sppm_begin: the call of the same name on every
+ * context at once.  sppm_iteration: one iteration on all GPUs; begin_next != 0
+ * also enqueues the light paths of iteration iter + 1 behind the exchange, under
+ * this iteration's gathers (pass 0 on the last iteration); stats is null or
+ * one TkIterStats per rank.  sppm_merge copies every rank's pixel rows into the
+ * context of rank 0 (tkhip_group_ctx(g, 0)), on which tkhip_sppm_resolve_rgb8,
+ * tkhip_sppm_read_pixels and tkhip_sppm_preview then see the whole image; the
+ * render can go on afterwards. */
+typedef struct tkhip_group tkhip_group;
+int tkhip_group_create(const int* devices, int n, tkhip_group** out);
+void tkhip_group_destroy(tkhip_group* g);
+int tkhip_group_size(const tkhip_group* g);
+tkhip_ctx* tkhip_group_ctx(tkhip_group* g, int rank);
+int tkhip_group_set_scene(tkhip_group* g,
+                          const TkObject* objects, int n_objects,
+                          const TkTriangle* tris, int n_tris,
+                          const TkSphere* spheres, int n_spheres,
+                          const TkMaterial* materials, int n_materials,
+                          const TkLight* lights, int n_lights);
+int tkhip_group_set_camera(tkhip_group* g, const float c2w[16], const float raster2cam[16],
+                           int width, int height);
+int tkhip_group_sppm_begin(tkhip_group* g, const TkSppmParam* param, int max_depth,
+                           float russian_roulette, uint64_t seed);
+int tkhip_group_sppm_iteration(tkhip_group* g, int iter, int begin_next, TkIterStats* stats);
+int tkhip_group_sppm_merge(tkhip_group* g);
 
 /* Cumulative shoot counters and the rounded-up iteration count. */
 int tkhip_sppm_counters(tkhip_ctx* ctx, int64_t* shoot_global, int64_t* shoot_caustic,

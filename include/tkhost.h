@@ -57,6 +57,13 @@ void tkhost_camera_config(const tkhost_scene* s, TkCameraConfig* out);
 void tkhost_image_config(const tkhost_scene* s, int* width, int* height, int* windows,
                          char* outfilename, size_t outfilename_cap);
 
+/* GPUs one render of this scene is spread over: the optional <gpus i="N"/>
+ * element of the scene root (an addition to the format parsed at
+ * src/TkLoader.cpp:387-390; default 1), or what tkhost_set_gpu_count set.
+ * With more ranks than GPUs the ranks share the GPUs round-robin. */
+int tkhost_gpu_count(const tkhost_scene* s);
+void tkhost_set_gpu_count(tkhost_scene* s, int gpus);
+
 /* CameraInfo::rotate(0,0) + setTranslation + perspective + Camera ctor
  * (src/TkRenderer.cpp:333-376, src/main.cpp:39-46, src/core/camera.cpp:10-20):
  * the two row-major matrices tkhip_set_camera takes. */

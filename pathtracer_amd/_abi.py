@@ -114,6 +114,18 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_resolve_rgb8": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p]),
     "tkhip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_bvh_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_float_p]),
+    "tkhip_device_count": (C.c_int, []),
+    "tkhip_group_create": (C.c_int, [c_int32_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "tkhip_group_destroy": (None, [C.c_void_p]),
+    "tkhip_group_size": (C.c_int, [C.c_void_p]),
+    "tkhip_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "tkhip_group_set_scene": (C.c_int, [C.c_void_p, C.POINTER(TkObject), C.c_int, C.POINTER(TkTriangle), C.c_int,
+                                        C.POINTER(TkSphere), C.c_int, C.POINTER(TkMaterial), C.c_int,
+                                        C.POINTER(TkLight), C.c_int]),
+    "tkhip_group_set_camera": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int]),
+    "tkhip_group_sppm_begin": (C.c_int, [C.c_void_p, C.POINTER(TkSppmParam), C.c_int, C.c_float, C.c_uint64]),
+    "tkhip_group_sppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(TkIterStats)]),
+    "tkhip_group_sppm_merge": (C.c_int, [C.c_void_p]),
     "tkhip_sppm_set_preview": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_preview": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_int32_p]),
     "tkhip_sppm_read_preview": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
@@ -167,6 +179,8 @@ TKHOST_SYMBOLS = {
                                 C.POINTER(C.c_double)]),
     "tkhost_render_windowed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_int,
                                          C.c_char_p, C.c_void_p]),
+    "tkhost_gpu_count": (C.c_int, [C.c_void_p]),
+    "tkhost_set_gpu_count": (None, [C.c_void_p, C.c_int]),
     "tkhost_write_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_uint8_p]),
 }
 

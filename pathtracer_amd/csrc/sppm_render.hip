@@ -1147,6 +1147,20 @@ static int sppm_begin_launches(tkhip_ctx* ctx, SppmState* s, const std::vector<i
     return TKHIP_OK;
 }
 
+namespace tkd {
+int sppm_local_photons(tkhip_ctx* ctx, int which, const void** pos, const void** pow, const void** dir, int64_t* n,
+                       int64_t* shot) {
+    TK_REQUIRE(ctx && ctx->sppm && (which == 0 || which == 1), TKHIP_E_STATE, "sppm_local_photons: no render on this context");
+    SppmState* s = ctx->sppm;
+    *pos = s->loc_pos[which].p;
+    *pow = s->loc_pow[which].p;
+    *dir = s->loc_dir[which].p;
+    *n = s->n_loc[which];
+    *shot = s->last_shot[which];
+    return TKHIP_OK;
+}
+}  // namespace tkd
+
 #define TK_CTX_SPPM(ctx, fn)                                                             \
     TK_REQUIRE((ctx) != nullptr, TKHIP_E_ARG, fn ": null context");                      \
     TK_REQUIRE((ctx)->sppm != nullptr, TKHIP_E_STATE, fn ": call tkhip_sppm_begin first"); \

@@ -108,6 +108,15 @@ int tkhip_create(int device, tkhip_ctx** out) {
     return TKHIP_OK;
 }
 
+int tkhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 void tkhip_destroy(tkhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

@@ -214,5 +214,9 @@ int upload_direction_tables(tkhip_ctx* ctx);
 // Looks up the address of the library's static gather scratch on `device` (which must be current).
 int static_scratch_init(int device);
 void destroy_sppm(tkhip_ctx* ctx);
+// The photons this rank's last photon pass stored for map `which` (arrays on the context's GPU:
+// 3 floats, 3 floats, 2 bytes per photon) and the light paths it shot for them.
+int sppm_local_photons(tkhip_ctx* ctx, int which, const void** pos, const void** pow, const void** dir, int64_t* n,
+                       int64_t* shot);
 
 }  // namespace tkd

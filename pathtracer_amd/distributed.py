@@ -198,18 +198,26 @@ def exchange_photons(backend, world):
     return totals
 
 
-def iteration(backend, it, world, stats=None):
-    """photon pass -> exchange -> tree builds -> camera pass (gathers), for every rank in lockstep."""
+def iteration(backend, it, world, stats=None, begin_next=False):
+    """photon pass -> exchange -> tree builds -> camera pass (gathers), for every rank in lockstep.
+    begin_next: the light paths of iteration it + 1 are enqueued right after the exchange (they depend on
+    nothing this iteration still computes) and run under its tree builds and gathers; the next call must
+    then be for it + 1."""
     if world == 1 and hasattr(backend, "iteration_single"):
         backend.iteration_single(it, stats)
         return [None, None]
     if hasattr(backend, "camera_begin"):
         # camera paths do not read the maps: trace them beside the photon phase, behind the light paths
         # in the GPU's queues (the exchange waits for those)
-        backend.photon_begin(it)
+        if getattr(backend, "_lights_begun", None) != it:
+            backend.photon_begin(it)
+        backend._lights_begun = None
         backend.camera_begin(it)
     backend.photon_pass(it, stats)
     totals = exchange_photons(backend, world)
+    if begin_next and hasattr(backend, "camera_begin"):
+        backend.photon_begin(it + 1)
+        backend._lights_begun = it + 1
     backend.build_maps(stats)
     backend.camera_pass(it, stats)
     return totals

@@ -15,15 +15,16 @@ using namespace tk;
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "Please input the scene file!\n"
-                        "usage: raytracer <file.scene> [--device N] [--width W] [--height H] [--seed S] [--out file.ppm]\n");
+                        "usage: raytracer <file.scene> [--device N] [--gpus N] [--width W] [--height H] [--seed S] [--out file.ppm]\n");
         return 0;
     }
     std::string inputfile = argv[1];
-    int device = 0, width = 0, height = 0;
+    int device = 0, width = 0, height = 0, gpus = 0;
     uint64_t seed = 0x5EED;
     std::string out;
     for (int i = 2; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--width")) width = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--height")) height = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], nullptr, 0);
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
     }
     Camera camera(config.camera, width, height);
     tracer->setDevice(device);
+    tracer->setGpuCount(gpus > 0 ? gpus : config.gpus);   // --gpus overrides the scene's <gpus i="N"/>
     tracer->setSeed(seed);
     tracer->setScene(&config.scene);
     tracer->setCamera(&camera);

@@ -40,11 +40,14 @@ protected:
     float mRussianRoulette;
     int mDevice = 0;
     uint64_t mSeed = 0x5EED;
-    tkhip_ctx* mCtx = nullptr;
+    tkhip_ctx* mCtx = nullptr;            // the context of rank 0 when mGroup is set (owned by the group then)
+    tkhip_group* mGroup = nullptr;        // more than one GPU: one context per rank
+    int mGpus = 1;
     std::string mError;
 
     bool fail(const char* what);          // records tkhip_last_error(), prints it, returns false
     bool uploadScene();
+    void releaseDevice();
     virtual void visualize() {}
     virtual void rendering() = 0;         // one step of the render state machine
 public:
@@ -52,6 +55,8 @@ public:
     virtual ~RayTracer();
     void setDevice(int device) { mDevice = device; }
     void setSeed(uint64_t seed) { mSeed = seed; }
+    // Ranks the render is spread over, on GPUs mDevice, mDevice + 1, ... (modulo the GPUs present).
+    void setGpuCount(int gpus) { mGpus = gpus < 1 ? 1 : gpus; }
     void setScene(const SceneData* scene);
     void setCamera(const Camera* camera);
     void updateScreen();
@@ -77,6 +82,8 @@ protected:
     bool mPreviewStale = false;           // the device frame buffer is newer than mFrameBuffer
     void rendering() override;
     bool resolve(std::vector<uint8_t>* rgb);
+    bool step(TkIterStats* st);           // one iteration on the context or on the group
+    bool mergeRanks();                    // group: every rank's pixel rows into rank 0's context
 public:
     SppmTracer(int spp, int maxDepth, int numThreads, float russianRoulette, TkSppmParam param);
     void startRaytracing() override;
@@ -85,7 +92,7 @@ public:
     const uint32_t* frameBuffer() override;
     // Progressive display: the device-resident frame buffer is refreshed after every n-th step of
     // updateScreen() / rendering() (call after startRaytracing; the windowed path uses 1).
-    bool setPreviewInterval(int n) { return mCtx && tkhip_sppm_set_preview(mCtx, n) == 0; }
+    bool setPreviewInterval(int n) { return mCtx && !mGroup && tkhip_sppm_set_preview(mCtx, n) == 0; }
     const std::vector<TkIterStats>& stats() const { return mStats; }
 };
 

@@ -372,6 +372,9 @@ void loadScene(Config* config, const std::string& filename) {
     childInt(root, false, "width", &config->width);
     childInt(root, false, "height", &config->height);
     childInt(root, false, "windows", &config->isWindows);
+    // not in the reference's format: how many GPUs to spread the render over (default 1)
+    childInt(root, false, "gpus", &config->gpus);
+    if (config->gpus < 1 || config->gpus > 64) throw std::runtime_error(filename + ": <gpus> must be between 1 and 64");
 
     // parse_camera, src/TkLoader.cpp:213-226
     const XmlNode* cam = uniqueChild(root, true, "camera");

@@ -29,6 +29,7 @@ struct Config {
     std::string outfilename;
     int width = 784;
     int height = 784;
+    int gpus = 1;   // <gpus i="N"/> in the scene root: GPUs one render is spread over (not in the reference's format)
 };
 
 // Row-major 4x4, m[row*4+col] (src/Matrix4.h:11-15).

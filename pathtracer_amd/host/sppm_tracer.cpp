@@ -19,8 +19,13 @@ RayTracer::RayTracer(int spp, int maxDepth, int numThreads, float russianRoulett
     mSpp = spp + 1;
 }
 
-RayTracer::~RayTracer() {
-    if (mCtx) tkhip_destroy(mCtx);
+RayTracer::~RayTracer() { releaseDevice(); }
+
+void RayTracer::releaseDevice() {
+    if (mGroup) tkhip_group_destroy(mGroup);   // destroys the contexts of all ranks, mCtx among them
+    else if (mCtx) tkhip_destroy(mCtx);
+    mGroup = nullptr;
+    mCtx = nullptr;
 }
 
 bool RayTracer::fail(const char* what) {
@@ -50,8 +55,28 @@ bool RayTracer::uploadScene() {
         mError = "setScene and setCamera must be called before rendering";
         return false;
     }
-    if (!mCtx && tkhip_create(mDevice, &mCtx) != 0) return fail("tkhip_create");
     const SceneData& s = *mScene;
+    if (mGpus > 1) {
+        const int present = tkhip_device_count();
+        if (present < 1) {
+            mError = "no GPU";
+            return false;
+        }
+        std::vector<int> devices;
+        for (int r = 0; r < mGpus; ++r) devices.push_back((mDevice + r) % present);
+        if (mGpus > present)
+            fprintf(stderr, "\r[Tracer] %d ranks on %d GPU(s): ranks share GPUs\n", mGpus, present);
+        if (!mGroup && tkhip_group_create(devices.data(), mGpus, &mGroup) != 0) return fail("tkhip_group_create");
+        mCtx = tkhip_group_ctx(mGroup, 0);
+        if (tkhip_group_set_scene(mGroup, s.objects.data(), int(s.objects.size()), s.tris.data(), int(s.tris.size()),
+                                  s.spheres.data(), int(s.spheres.size()), s.materials.data(), int(s.materials.size()),
+                                  s.lights.data(), int(s.lights.size())) != 0)
+            return fail("tkhip_group_set_scene");
+        if (tkhip_group_set_camera(mGroup, mCamera->c2w, mCamera->rasterToCamera, mWidth, mHeight) != 0)
+            return fail("tkhip_group_set_camera");
+        return true;
+    }
+    if (!mCtx && tkhip_create(mDevice, &mCtx) != 0) return fail("tkhip_create");
     if (tkhip_set_scene(mCtx, s.objects.data(), int(s.objects.size()), s.tris.data(), int(s.tris.size()),
                         s.spheres.data(), int(s.spheres.size()), s.materials.data(), int(s.materials.size()),
                         s.lights.data(), int(s.lights.size())) != 0)
@@ -111,18 +136,21 @@ void SppmTracer::startRaytracing() {
     if (mState != READY) return;
     curRecurse = 0;
     mStats.clear();
-    if (mCtx) {   // a fresh context per render keeps the state machine simple
-        tkhip_destroy(mCtx);
-        mCtx = nullptr;
-    }
+    releaseDevice();   // a fresh context per render keeps the state machine simple
     if (!uploadScene()) return;
-    if (tkhip_sppm_begin(mCtx, &mParam, mMaxDepth, mRussianRoulette, mSeed, 0, 1) != 0) {
+    if (mGroup) {
+        if (tkhip_group_sppm_begin(mGroup, &mParam, mMaxDepth, mRussianRoulette, mSeed) != 0) {
+            fail("tkhip_group_sppm_begin");
+            return;
+        }
+    } else if (tkhip_sppm_begin(mCtx, &mParam, mMaxDepth, mRussianRoulette, mSeed, 0, 1) != 0) {
         fail("tkhip_sppm_begin");
         return;
     }
-    fprintf(stderr, "\r[Tracer] device %d, %dx%d, %d iterations\n", mDevice, mWidth, mHeight, numRecurse);
-    // The windowed path shows every iteration; the frame buffer is refreshed on the device.
-    if (tkhip_sppm_set_preview(mCtx, 1) != 0) {
+    fprintf(stderr, "\r[Tracer] device %d, %d GPU rank(s), %dx%d, %d iterations\n", mDevice, mGpus, mWidth, mHeight, numRecurse);
+    // The windowed path shows every iteration; the frame buffer is refreshed on the device (with several
+    // ranks: when somebody asks for it, after their rows have been merged).
+    if (!mGroup && tkhip_sppm_set_preview(mCtx, 1) != 0) {
         fail("tkhip_sppm_set_preview");
         return;
     }
@@ -130,7 +158,25 @@ void SppmTracer::startRaytracing() {
     RayTracer::startRaytracing();
 }
 
+bool SppmTracer::mergeRanks() {
+    if (mGroup && tkhip_group_sppm_merge(mGroup) != 0) return fail("tkhip_group_sppm_merge");
+    return true;
+}
+
+bool SppmTracer::step(TkIterStats* st) {
+    if (mGroup) {
+        std::vector<TkIterStats> per_rank(st ? size_t(mGpus) : 0);
+        if (tkhip_group_sppm_iteration(mGroup, curRecurse, curRecurse + 1 < numRecurse, st ? per_rank.data() : nullptr) != 0)
+            return fail("tkhip_group_sppm_iteration");
+        if (st) *st = per_rank[0];
+        return true;
+    }
+    if (tkhip_sppm_iteration(mCtx, curRecurse, st) != 0) return fail("tkhip_sppm_iteration");
+    return true;
+}
+
 bool SppmTracer::resolve(std::vector<uint8_t>* rgb) {
+    if (!mergeRanks()) return false;
     rgb->resize(size_t(mWidth) * size_t(mHeight) * 3);
     if (tkhip_sppm_resolve_rgb8(mCtx, numRecurse, rgb->data()) != 0) return fail("tkhip_sppm_resolve_rgb8");
     return true;
@@ -143,8 +189,7 @@ void SppmTracer::rendering() {
     if (mState != RENDERING) return;
     TkIterStats st;
     memset(&st, 0, sizeof(st));
-    if (tkhip_sppm_iteration(mCtx, curRecurse, &st) != 0) {
-        fail("tkhip_sppm_iteration");
+    if (!step(&st)) {
         mState = READY;
         return;
     }
@@ -166,7 +211,8 @@ void SppmTracer::rendering() {
 const uint32_t* SppmTracer::frameBuffer() {
     if (mPreviewStale && mCtx) {
         int shown = -1;
-        if (tkhip_sppm_read_preview(mCtx, mFrameBuffer.data(), &shown) != 0) fail("tkhip_sppm_read_preview");
+        if (mGroup && (!mergeRanks() || tkhip_sppm_preview(mCtx, 1, nullptr, nullptr) != 0)) fail("tkhip_sppm_preview");
+        else if (tkhip_sppm_read_preview(mCtx, mFrameBuffer.data(), &shown) != 0) fail("tkhip_sppm_read_preview");
         mPreviewStale = false;
     }
     return mFrameBuffer.data();
@@ -181,7 +227,8 @@ void SppmTracer::saveImage(std::string filename) {
     if (mState == RENDERING) {
         int shown = -1;
         std::vector<uint32_t> fb(size_t(mWidth) * size_t(mHeight));
-        if (tkhip_sppm_preview(mCtx, 1, nullptr, nullptr) != 0 || tkhip_sppm_read_preview(mCtx, fb.data(), &shown) != 0) {
+        if (!mergeRanks() || tkhip_sppm_preview(mCtx, 1, nullptr, nullptr) != 0 ||
+            tkhip_sppm_read_preview(mCtx, fb.data(), &shown) != 0) {
             fail("tkhip_sppm_read_preview");
             return;
         }
@@ -209,11 +256,10 @@ void SppmTracer::render(std::string filename) {
     if (want_stats && atoi(want_stats) != 0) {
         while (mState == RENDERING) rendering();
     } else {
-        if (mState == RENDERING && tkhip_sppm_set_preview(mCtx, 0) != 0) fail("tkhip_sppm_set_preview");
+        if (mState == RENDERING && !mGroup && tkhip_sppm_set_preview(mCtx, 0) != 0) fail("tkhip_sppm_set_preview");
         int64_t shot[2] = {0, 0};
         while (mState == RENDERING) {
-            if (tkhip_sppm_iteration(mCtx, curRecurse, nullptr) != 0) {
-                fail("tkhip_sppm_iteration");
+            if (!step(nullptr)) {
                 mState = READY;
                 return;
             }
@@ -259,6 +305,7 @@ extern "C" int tkhost_render(tkhost_scene* s, int device, int width, int height,
     }
     tk::Camera camera(cfg.camera, w, h);
     tracer->setDevice(device);
+    tracer->setGpuCount(cfg.gpus);
     tracer->setSeed(seed);
     tracer->setScene(&cfg.scene);
     tracer->setCamera(&camera);
@@ -293,6 +340,7 @@ extern "C" int tkhost_render_windowed(tkhost_scene* s, int device, int width, in
     }
     tk::Camera camera(cfg.camera, w, h);
     tracer->setDevice(device);
+    tracer->setGpuCount(cfg.gpus);
     tracer->setSeed(seed);
     tracer->setScene(&cfg.scene);
     tracer->setCamera(&camera);

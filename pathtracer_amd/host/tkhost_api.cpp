@@ -74,6 +74,11 @@ const TkLight* tkhost_lights(const tkhost_scene* s, int* n) {
 
 void tkhost_tracer_config(const tkhost_scene* s, TkTracerConfig* out) { *out = s->config.tracer; }
 void tkhost_camera_config(const tkhost_scene* s, TkCameraConfig* out) { *out = s->config.camera; }
+int tkhost_gpu_count(const tkhost_scene* s) { return s ? s->config.gpus : 0; }
+void tkhost_set_gpu_count(tkhost_scene* s, int gpus) {
+    if (s && gpus >= 1 && gpus <= 64) s->config.gpus = gpus;
+}
+
 void tkhost_image_config(const tkhost_scene* s, int* width, int* height, int* windows, char* outfilename,
                          size_t cap) {
     if (width) *width = s->config.width;

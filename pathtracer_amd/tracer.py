@@ -375,3 +375,58 @@ class SppmTracer:
         if self.ctx:
             self.ctx.close()
             self.ctx = None
+
+
+class SppmGroup:
+    """One SPPM render over several GPUs of this process (tkhip_group_*): one context and one host thread per
+    rank inside the library, photons exchanged with peer copies.  `devices` may repeat a GPU."""
+
+    def __init__(self, scene, devices, param, max_depth, rr, width, height, seed=0x5EED):
+        self.lib = _abi.load_tkhip()
+        lib = self.lib
+        dev = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        check(lib, lib.tkhip_group_create(dev, len(devices), C.byref(h)), "tkhip_group_create")
+        self.h, self.world, self.width, self.height, self.scene = h, len(devices), width, height, scene
+        check(lib, lib.tkhip_group_set_scene(h, scene.objects, scene.n_objects, scene.triangles, scene.n_triangles,
+                                             scene.spheres, scene.n_spheres, scene.materials, scene.n_materials,
+                                             scene.lights, scene.n_lights), "tkhip_group_set_scene")
+        c2w, r2c = scene.camera_matrices(width, height)
+        check(lib, lib.tkhip_group_set_camera(h, _fp(c2w), _fp(r2c), width, height), "tkhip_group_set_camera")
+        self.param = param
+        check(lib, lib.tkhip_group_sppm_begin(h, C.byref(param), max_depth, rr, seed), "tkhip_group_sppm_begin")
+        self.ctx0 = lib.tkhip_group_ctx(h, 0)
+
+    def iteration(self, it, begin_next=False, with_stats=False):
+        stats = (_abi.TkIterStats * self.world)() if with_stats else None
+        check(self.lib, self.lib.tkhip_group_sppm_iteration(self.h, it, 1 if begin_next else 0, stats),
+              "tkhip_group_sppm_iteration")
+        return stats
+
+    def merge(self):
+        check(self.lib, self.lib.tkhip_group_sppm_merge(self.h), "tkhip_group_sppm_merge")
+
+    def pixels(self):
+        """The merged SPPMPixel array, (width*height, 13) float32."""
+        self.merge()
+        n = self.width * self.height
+        buf = (_abi.TkSPPMPixel * n)()
+        check(self.lib, self.lib.tkhip_sppm_read_pixels(self.ctx0, buf), "tkhip_sppm_read_pixels")
+        return np.frombuffer(buf, dtype=np.float32).reshape(n, 13).copy()
+
+    def resolve(self, iterations):
+        self.merge()
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        check(self.lib, self.lib.tkhip_sppm_resolve_rgb8(self.ctx0, iterations, _bp(out)), "tkhip_sppm_resolve_rgb8")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tkhip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
