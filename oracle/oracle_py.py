@@ -1,7 +1,7 @@
 """ctypes wrapper of oracle/liboracle.so — TEST INFRASTRUCTURE.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
-this module.  PARITY UNPINNED: see oracle/sppm_oracle.h.
+this module.  How the oracle is pinned to the reference: see oracle/sppm_oracle.h.
 """
 import ctypes as C
 import os

@@ -1,8 +1,9 @@
 /*
  * sppm_oracle.c — CPU restatement of the reference SPPM iteration, in plain C.
  *
- * TEST INFRASTRUCTURE ONLY (see sppm_oracle.h).  PARITY UNPINNED: the
- * reference holds no tests or golden vectors for this path.  Every function
+ * TEST INFRASTRUCTURE ONLY (see sppm_oracle.h).  Pinned to outputs of the
+ * reference built headless (oracle/build_ref.sh, oracle/ref_probe.cpp,
+ * tests/golden/ref_*.npz, tests/test_ref_pinned_cpu.py).  Every function
  * cites the reference lines it restates (paths relative to the upstream
  * repository root).  Build with -ffp-contract=off: the reference binary is
  * baseline x86-64 (no FMA), so products and sums round separately.

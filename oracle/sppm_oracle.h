@@ -4,10 +4,17 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; the product (libtkhip.so, libtkhost.so) never does.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
- * for this path, and its sources do not compile in this image without
- * stand-in GL headers and source edits, so this restatement is checked by
- * reading it against the cited reference lines, not against reference output.
+ * PINNED: the reference ships no tests or fixtures of its own, but the part
+ * of it this path uses compiles without a window (oracle/build_ref.sh: its own
+ * translation units and its own vendored GL/glew.h, nothing stood in).  A
+ * prober (oracle/ref_probe.cpp) calls the reference's functions on seeded
+ * inputs; the outputs are committed as tests/golden/ref_*.npz
+ * (oracle/make_ref_golden.py) and tests/test_ref_pinned_cpu.py holds this
+ * restatement to them: bit-exact for hits, indices, radii and counts.
+ * Not pinned, because no reference output can exist for them: the camera
+ * matrices of CameraInfo (src/TkRenderer.cpp needs GL/glu.h), the photon
+ * loops as a whole (unseeded random numbers) and the rule for photons tied at
+ * the k-th distance.
  *
  * The scene/parameter/pixel structs are the data formats of include/tkhip.h.
  */

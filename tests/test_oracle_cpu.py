@@ -205,6 +205,25 @@ def test_resolve_formula_and_row_flip():
     assert out[0, 0].sum() == 0
 
 
+def test_resolve_with_more_than_2_31_light_paths():
+    """The reference counts its light paths in an s32 (src/tracer/TkSppmTracer.h:31-32) that wraps after 2^31 of
+    them; here the totals are 64-bit and converted to float, so a long render keeps dividing by the true count:
+    flux scaled with the count gives the same pixel below and above 2^31."""
+    w, h = 1, 1
+    out_small = np.zeros((h, w, 3), np.uint8)
+    out_big = np.zeros((h, w, 3), np.uint8)
+    for shoot, out in ((1 << 20, out_small), ((1 << 31) + (1 << 20), out_big)):
+        px = (_abi.TkSPPMPixel * 1)()
+        px[0].causticRadius2 = px[0].globalRadius2 = 0.05
+        for c in range(3):
+            px[0].globalFlux[c] = math.pi * 0.05 * float(shoot) * 0.5
+            px[0].causticFlux[c] = math.pi * 0.05 * float(shoot) * 0.125
+        L.orc_resolve_rgb8(px, w, h, 4, shoot, shoot, 1, O.bp(out))
+    want = int(255 * 0.625 ** 0.6)
+    assert abs(int(out_small[0, 0, 0]) - want) <= 1
+    assert (out_big == out_small).all()          # an s32 would have made the divisor negative here
+
+
 # ---------------------------------------------------------------- geometry
 def _single_triangle_scene():
     tri = (_abi.TkTriangle * 1)()
