@@ -322,6 +322,26 @@ int tkhip_sppm_set_preview(tkhip_ctx* ctx, int every_n);
 int tkhip_sppm_preview(tkhip_ctx* ctx, int refresh, const uint32_t** device_rgba, int* iteration);
 int tkhip_sppm_read_preview(tkhip_ctx* ctx, uint32_t* host_rgba, int* iteration);
 
+/* ------------------------------------------------ hash-grid variant: tk::SPPM
+ * The reference's second SPPM class (src/TkSPPM.h:10-64, src/TkSPPM.cpp): per
+ * iteration a ray pass that leaves one visible point per pixel (traceTile,
+ * :136-179), a spatial hash grid over the visible points (SpatialHashGrids,
+ * :19-112), a photon pass of photonsPerIt = param->globalSize light paths that
+ * deposit into the pixels they reach (tracePhoton, :181-250) and the per-pixel
+ * radius reduction (updatePixel, :252-272).  It is selected by swapping the
+ * commented line at src/TkLoader.cpp:249-250 and is not in the reference's
+ * build.  param->radius2 is the initial RADIUS here (SPPM's constructor reads it
+ * so, :117), causticSize / the sample counts are unused; spp is RayTracer's spp
+ * (a power of two), by which every direct-light term is divided.
+ * tkhip_sppm_read_pixels then reports: Ld = Ld, causticFlux = Tau,
+ * causticPhotons = N, causticRadius2 = the radius (not squared).
+ * stats: rays, global_paths, shoot_global, gathers_caustic = visible points. */
+int tkhip_hsppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int spp, int max_depth,
+                      float russian_roulette, uint64_t seed);
+int tkhip_hsppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* stats);
+/* Final image of SPPM::render (src/TkSPPM.cpp:436-450): RGB8, rows bottom-up. */
+int tkhip_hsppm_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out);
+
 /* ------------------------------------------------ several GPUs, one process
  * The reference spreads an iteration over the threads of one machine (TkSpawn /
  * TkWait, src/Threads.cpp:19-56, called from src/tracer/TkSppmTracer.cpp:411-438

@@ -70,6 +70,8 @@ def lib():
         "orc_sppm_read_pixels": (None, [C.c_void_p, C.POINTER(_abi.TkSPPMPixel)]),
         "orc_sppm_write_pixels": (None, [C.c_void_p, C.POINTER(_abi.TkSPPMPixel)]),
         "orc_sppm_resolve": (None, [C.c_void_p, u8p]),
+        "orc_hsppm_iteration": (None, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+        "orc_hsppm_resolve": (None, [C.c_void_p, u8p]),
         "orc_sppm_read_photons": (C.c_int64, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, i64p]),
         "orc_sppm_set_map_photons": (None, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, C.c_int64, C.c_int64]),
         "orc_sppm_counters": (None, [C.c_void_p, i64p, i64p, i32p]),
@@ -230,6 +232,17 @@ class OracleSppm:
     def resolve(self):
         out = np.empty((self.oscene.height, self.oscene.width, 3), np.uint8)
         lib().orc_sppm_resolve(self.h, bp(out))
+        return out
+
+    # hash-grid variant (tk::SPPM): the same state driven by orc_hsppm_*
+    def hash_iteration(self, spp, it):
+        st = (C.c_int64 * 3)()
+        lib().orc_hsppm_iteration(self.h, spp, it, st)
+        return list(st)
+
+    def hash_resolve(self):
+        out = np.empty((self.oscene.height, self.oscene.width, 3), np.uint8)
+        lib().orc_hsppm_resolve(self.h, bp(out))
         return out
 
     def photons(self, which, capacity):

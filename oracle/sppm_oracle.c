@@ -1812,3 +1812,238 @@ void orc_sppm_counters(orc_sppm* r, int64_t* sg, int64_t* sc, int32_t* nr) {
     if (sc) *sc = r->shoot_c;
     if (nr) *nr = r->num_recurse;
 }
+
+/* ===================================================================== hash-grid SPPM
+ * tk::SPPM (src/TkSPPM.h:10-64, src/TkSPPM.cpp:19-272, :347-465): visible point per pixel, spatial
+ * hash grid over the visible points, photons deposited into the pixels they reach, per-pixel
+ * radius reduction.  The class is not part of the reference's build (absent from
+ * src/CMakeLists.txt, its line in src/TkLoader.cpp:250 commented out, written against an older
+ * RayTracer interface), so no reference output exists for it: PARITY UNPINNED beyond the building
+ * blocks it shares with SppmTracer (intersection, materials, light sampling, samplers).
+ * An orc_sppm created with causticSize 0 carries the state; the TkSPPMPixel fields are reused:
+ * Ld = Ld, causticFlux = Tau, causticPhotons = N, causticRadius2 = radius (not squared). */
+typedef struct { v3 p, n, wo, thr; const TkMaterial* m; float radius; int pixel; } VisPoint;
+
+static uint32_t hg_hash(int x, int y, int z, uint32_t buckets) {             /* src/TkSPPM.cpp:109-112 */
+    int32_t h = (int32_t)(((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349663u) ^ ((uint32_t)z * 83492791u));
+    return (uint32_t)((uint64_t)(int64_t)h % (uint64_t)buckets);             /* s32 widened to size_t */
+}
+typedef struct { box3 b; int res[3]; int valid; } HashGrid;
+static int hg_world_to_grid(const HashGrid* g, v3 p, int pi[3]) {            /* src/TkSPPM.cpp:88-99 */
+    float o[3] = {p.x - g->b.mn.x, p.y - g->b.mn.y, p.z - g->b.mn.z};        /* Bounds3::Offset */
+    float mn[3] = {g->b.mn.x, g->b.mn.y, g->b.mn.z}, mx[3] = {g->b.mx.x, g->b.mx.y, g->b.mx.z};
+    int in = 1;
+    for (int i = 0; i < 3; ++i) {
+        if (mx[i] > mn[i]) o[i] /= mx[i] - mn[i];
+        pi[i] = (int)((float)g->res[i] * o[i]);
+        in &= (pi[i] >= 0 && pi[i] < g->res[i]);
+        pi[i] = pi[i] < 0 ? 0 : (pi[i] > g->res[i] - 1 ? g->res[i] - 1 : pi[i]);
+    }
+    return in;
+}
+
+/* One pixel of SPPM::traceTile, src/TkSPPM.cpp:140-177.  Returns 1 with *vp filled when the path
+ * ends on a diffuse surface. */
+static int hsppm_camera_path(const orc_sppm* r, int spp, int iter, int x, int y, TkSPPMPixel* p, VisPoint* vp, TraceCounters* tc) {
+    const orc_scene* s = r->sc;
+    Sampler sm;
+    sm.px = x; sm.py = y; sm.sample_idx = iter; sm.spp = r->num_recurse; sm.xs = r->xs; sm.ys = r->ys;
+    sm.dim = 0; sm.seed = 0;
+    sm.rng_seed = r->seed; sm.rng_pixel = (uint32_t)(x + y * s->w); sm.rng_iter = (uint32_t)iter; sm.rng_cost = r->rng_cost; sm.no_jitter = r->no_jitter;
+    float cx, cy, lx, ly;
+    sampler_get2d(&sm, &cx, &cy);
+    cx = cx + (float)x; cy = cy + (float)y;
+    sampler_get2d(&sm, &lx, &ly);
+    Ray ray = camera_ray(s, cx, cy);
+    v3 coef = V(1.f, 1.f, 1.f);
+    int has_specular = 1, found = 0;
+    for (int i = 0; i < r->max_depth; ++i) {
+        Isect is; memset(&is, 0, sizeof(is));
+        if (!scene_intersect(s, &ray, &is, r->faithful, tc)) break;
+        const TkObject* ob = &s->objects[is.obj];
+        const TkMaterial* m = &s->mats[ob->material];
+        int diffuse = m->type == TK_DIFFUSE;
+        v3 wo = vneg(ray.d);
+        v3 Ld = V(0, 0, 0);
+        if (has_specular && ob->light >= 0) Ld = vadd(Ld, vmul(coef, light_L(&s->lights[ob->light], is.n, wo)));
+        Ld = vadd(Ld, vmul(coef, uniform_sample_one_light(r, &is, &sm, tc)));
+        Ld = vdivs(Ld, (float)spp);                       /* spp is a power of two: same as dividing each term */
+        p->Ld[0] += Ld.x; p->Ld[1] += Ld.y; p->Ld[2] += Ld.z;
+        if (diffuse) {
+            vp->p = is.p; vp->n = is.n; vp->wo = is.wo; vp->thr = coef; vp->m = m;
+            vp->radius = p->causticRadius2; vp->pixel = x + y * s->w;
+            found = 1;
+            break;
+        }
+        has_specular &= (m->type & (TK_MIRROR | TK_GLASS)) != 0;
+        v3 wi; float pdf;
+        float ux, uy;
+        sampler_get2d(&sm, &ux, &uy);
+        v3 f = mat_sample_f(m, 0, wo, &wi, is.n, ux, uy, &pdf);
+        if ((f.x == 0 && f.y == 0 && f.z == 0) || pdf == 0) break;
+        coef = vdivs(vscale(vmul(coef, f), vabsdot(wi, is.n)), pdf);
+        ray = spawn_ray(&is, wi);
+    }
+    return found;
+}
+
+typedef struct { orc_sppm* r; int spp, iter; VisPoint* vis; uint8_t* has; TraceCounters* tcs; } HCamJob;
+static void hsppm_row_job(void* a, int64_t y, int tid) {
+    HCamJob* j = (HCamJob*)a;
+    orc_sppm* r = j->r;
+    int w = r->sc->w;
+    for (int x = 0; x < w; ++x) {
+        int px = x + (int)y * w;
+        j->has[px] = (uint8_t)hsppm_camera_path(r, j->spp, j->iter, x, (int)y, &r->pp[px], &j->vis[px], &j->tcs[tid]);
+    }
+}
+
+/* One iteration of SPPM::render, src/TkSPPM.cpp:347-431: ray pass, grid rebuild, photon pass, renew
+ * pass.  Photons are traced one after the other in index order (the reference's threads interleave
+ * them under a mutex), the Russian roulette draws are hashed as everywhere in this file.
+ * stats[0] = visible points, [1] = grid entries, [2] = photon deposits (sum of M). */
+void orc_hsppm_iteration(orc_sppm* r, int spp, int iter, int64_t stats[3]) {
+    const orc_scene* s = r->sc;
+    const int np = s->w * s->h;
+    int T = r->threads < 1 ? 1 : (r->threads > 256 ? 256 : r->threads);
+    VisPoint* vis = (VisPoint*)calloc((size_t)np, sizeof(VisPoint));
+    uint8_t* has = (uint8_t*)calloc((size_t)np, 1);
+    TraceCounters* tcs = (TraceCounters*)calloc((size_t)T, sizeof(TraceCounters));
+    HCamJob job = {r, spp, iter, vis, has, tcs};
+    parallel_for(T, s->h, 1, hsppm_row_job, &job);
+    free(tcs);
+    /* rebuild, src/TkSPPM.cpp:45-86 */
+    HashGrid g; g.b = box_empty(); g.valid = 0;
+    float max_radius = -INFINITY;
+    int64_t nvis = 0;
+    for (int i = 0; i < np; ++i) if (has[i]) {
+        v3 rr3 = V(vis[i].radius, vis[i].radius, vis[i].radius);
+        g.b = box_union_p(g.b, vsub(vis[i].p, rr3));
+        g.b = box_union_p(g.b, vadd(vis[i].p, rr3));
+        max_radius = tk_max(max_radius, vis[i].radius);
+        ++nvis;
+    }
+    const uint32_t buckets = (uint32_t)np;
+    int32_t* start = (int32_t*)calloc((size_t)buckets + 1, sizeof(int32_t));
+    int32_t* fill = (int32_t*)calloc((size_t)buckets + 1, sizeof(int32_t));
+    int32_t* items = 0;
+    int64_t entries = 0;
+    if (nvis > 0) {
+        g.valid = 1;
+        v3 diag = vsub(g.b.mx, g.b.mn);
+        int ext = box_max_extent(g.b);
+        float max_diag = vget(diag, ext);
+        int base = (int)(max_diag / max_radius);
+        for (int a = 0; a < 3; ++a) {
+            int rs = (int)((float)base * vget(diag, a) / max_diag);
+            g.res[a] = rs > 1 ? rs : 1;
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < np; ++i) if (has[i]) {
+                v3 rr3 = V(vis[i].radius, vis[i].radius, vis[i].radius);
+                int lo[3], hi[3];
+                hg_world_to_grid(&g, vsub(vis[i].p, rr3), lo);
+                hg_world_to_grid(&g, vadd(vis[i].p, rr3), hi);
+                for (int z = lo[2]; z <= hi[2]; ++z)
+                    for (int y = lo[1]; y <= hi[1]; ++y)
+                        for (int x = lo[0]; x <= hi[0]; ++x) {
+                            uint32_t b = hg_hash(x, y, z, buckets);
+                            if (pass == 0) start[b + 1]++;
+                            else items[start[b] + fill[b]++] = i;
+                        }
+            }
+            if (pass == 0) {
+                for (uint32_t b = 0; b < buckets; ++b) start[b + 1] += start[b];
+                entries = start[buckets];
+                items = (int32_t*)malloc(sizeof(int32_t) * (size_t)(entries ? entries : 1));
+            }
+        }
+    }
+    /* photon pass, src/TkSPPM.cpp:181-250 */
+    float* phi = (float*)calloc((size_t)np * 3, sizeof(float));
+    int32_t* M = (int32_t*)calloc((size_t)np, sizeof(int32_t));
+    const int64_t per_it = r->prm.globalSize;
+    int64_t deposits = 0;
+    TraceCounters tc; memset(&tc, 0, sizeof(tc));
+    const int nl = s->n_lights;
+    for (int64_t k = 0; k < per_it && nl > 0; ++k) {
+        uint64_t H = (uint64_t)iter * (uint64_t)per_it + (uint64_t)k;
+        int dim = 0;
+        int li = (int)(orc_radical_inverse(dim++, H) * nl);
+        if (li > nl - 1) li = nl - 1;
+        float pdf = 1.0f / nl;
+        float u0x = orc_radical_inverse(dim, H), u0y = orc_radical_inverse(dim + 1, H);
+        float u1x = orc_radical_inverse(dim + 2, H), u1y = orc_radical_inverse(dim + 3, H);
+        dim += 4;
+        Ray ray; v3 normal; float pos_pdf, dir_pdf;
+        float upick = photon_rng(r, H, 2, 0, 0);
+        v3 weight = light_sample_le(s, li, u0x, u0y, u1x, u1y, upick, &ray, &normal, &pos_pdf, &dir_pdf);
+        if (pos_pdf == 0 || dir_pdf == 0) continue;   /* the reference returns from its whole batch here; a light with zero pdf does not occur */
+        weight = vdivs(vscale(weight, vabsdot(ray.d, normal)), pos_pdf * dir_pdf * pdf);
+        for (int i = 0; i < r->max_depth; ++i) {
+            Isect is; memset(&is, 0, sizeof(is));
+            if (!scene_intersect(s, &ray, &is, r->faithful, &tc)) break;
+            v3 wo = vneg(ray.d);
+            if (i > 0 && g.valid) {
+                int pi[3];
+                if (hg_world_to_grid(&g, is.p, pi)) {
+                    uint32_t b = hg_hash(pi[0], pi[1], pi[2], buckets);
+                    for (int32_t e = start[b]; e < start[b + 1]; ++e) {
+                        VisPoint* v = &vis[items[e]];
+                        v3 d = vsub(v->p, is.p);
+                        if (vdot(d, d) <= v->radius * v->radius) {
+                            M[items[e]]++; ++deposits;
+                            v3 f = mat_f(v->m, v->wo, wo, v->n);
+                            phi[3 * items[e]] += f.x * weight.x;
+                            phi[3 * items[e] + 1] += f.y * weight.y;
+                            phi[3 * items[e] + 2] += f.z * weight.z;
+                        }
+                    }
+                }
+            }
+            if (photon_rng(r, H, 2, i, 1) > r->rr) break;
+            v3 wi; float bpdf = 0;
+            float ux = orc_radical_inverse(dim, H), uy = orc_radical_inverse(dim + 1, H);   /* the same two dimensions at every bounce, as there */
+            const TkMaterial* m = &s->mats[s->objects[is.obj].material];
+            v3 f = mat_sample_f(m, 1, wo, &wi, is.n, ux, uy, &bpdf);
+            if (bpdf == 0 || (f.x == 0 && f.y == 0 && f.z == 0)) break;
+            weight = vdivs(vscale(vmul(weight, f), vabsdot(wi, is.n)), bpdf * r->rr);
+            ray = spawn_ray(&is, wi);
+        }
+    }
+    r->shoot_g += per_it;
+    r->tc_photon[0] += tc.rays; r->tc_photon[1] += tc.nodes; r->tc_photon[2] += tc.prims;
+    /* renew pass, src/TkSPPM.cpp:252-272 */
+    for (int i = 0; i < np; ++i) {
+        if (!has[i] || M[i] <= 0) continue;
+        TkSPPMPixel* p = &r->pp[i];
+        const float alpha = 0.7f;
+        float N = p->causticPhotons, radius = p->causticRadius2;
+        float newN = N + alpha * (float)M[i];
+        float newR = radius * sqrtf(newN / (N + (float)M[i]));
+        float thr[3] = {vis[i].thr.x, vis[i].thr.y, vis[i].thr.z};
+        for (int c = 0; c < 3; ++c)
+            p->causticFlux[c] = (p->causticFlux[c] + thr[c] * phi[3 * i + c]) * (newR * newR) / (radius * radius);
+        p->causticPhotons = newN;
+        p->causticRadius2 = newR;
+    }
+    if (stats) { stats[0] = nvis; stats[1] = entries; stats[2] = deposits; }
+    free(vis); free(has); free(start); free(fill); free(items); free(phi); free(M);
+}
+
+/* The final image of SPPM::render, src/TkSPPM.cpp:436-450 (rows bottom-up). */
+void orc_hsppm_resolve(orc_sppm* r, uint8_t* out) {
+    const orc_scene* s = r->sc;
+    int off = 0;
+    for (int y = s->h; y-- > 0;)
+        for (int x = 0; x < s->w; ++x) {
+            const TkSPPMPixel* p = &r->pp[x + y * s->w];
+            float radius = p->causticRadius2;
+            float denom = (float)(r->num_recurse * r->prm.globalSize) * k_pi * radius * radius;
+            for (int c = 0; c < 3; ++c) {
+                float v = p->Ld[c] / (float)r->num_recurse + p->causticFlux[c] / denom;
+                float cl = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                out[off++] = (uint8_t)(255 * powf(cl, 0.6f));
+            }
+        }
+}

@@ -131,6 +131,13 @@ typedef struct OrcQuery {
 } OrcQuery;
 int orc_sppm_camera_path(orc_sppm* r, int iter, int x, int y, float ld_out[3], OrcQuery q[2]);
 
+/* --- hash-grid variant, tk::SPPM (src/TkSPPM.cpp) on an orc_sppm begun with causticSize 0.
+ * Not part of the reference's build, so unpinned beyond the shared building blocks.  Pixel fields:
+ * Ld = Ld, causticFlux = Tau, causticPhotons = N, causticRadius2 = radius (not squared).
+ * stats: visible points, grid entries, photon deposits. */
+void orc_hsppm_iteration(orc_sppm* r, int spp, int iter, int64_t stats[3]);
+void orc_hsppm_resolve(orc_sppm* r, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,9 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_resolve_rgb8": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p]),
     "tkhip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_bvh_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_float_p]),
+    "tkhip_hsppm_begin": (C.c_int, [C.c_void_p, C.POINTER(TkSppmParam), C.c_int, C.c_int, C.c_float, C.c_uint64]),
+    "tkhip_hsppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
+    "tkhip_hsppm_resolve_rgb8": (C.c_int, [C.c_void_p, c_uint8_p]),
     "tkhip_device_count": (C.c_int, []),
     "tkhip_group_create": (C.c_int, [c_int32_p, C.c_int, C.POINTER(C.c_void_p)]),
     "tkhip_group_destroy": (None, [C.c_void_p]),

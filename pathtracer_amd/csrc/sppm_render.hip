@@ -142,6 +142,10 @@ struct SppmState {
     int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
     DevBuf qbuf[2];
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
+    // hash-grid variant (tkhip_hsppm_*)
+    bool hashgrid = false;
+    int hg_spp = 1;
+    DevBuf hg_prm, hg_bounds, hg_count, hg_start, hg_cursor, hg_items, hg_phi, hg_m;
     DevBuf preview;                  // RGBA8 frame buffer on the device (tkhip_sppm_set_preview)
     int preview_every = 0, preview_iter = -1;
 };
@@ -166,8 +170,71 @@ TKD int queue_push(const PathQueue& q, int32_t* counters, bool want, bool specul
 }
 TKD int queue_index(const PathQueue& q, int w, int n_front) { return w < n_front ? w : q.cap - 1 - (w - n_front); }
 
+// ------------------------------------------------- hash grid of visible points
+// SpatialHashGrids of the reference's second SPPM class (src/TkSPPM.cpp:19-112): the visible point of
+// every pixel is listed in all the cells its search box overlaps, cells are hashed into as many
+// buckets as the image has pixels.  Here the buckets are one array in bucket order (start / items).
+struct HashGridParams {
+    float bmin[3], bmax[3];
+    int32_t res[3];
+    int32_t valid;            // 0: no visible point this iteration
+};
+struct HashGridView {
+    const HashGridParams* prm;
+    const int32_t* start;     // buckets + 1
+    const int32_t* items;     // visible-point numbers, bucket by bucket
+    const float4* vp0;        // position, radius
+    const float4* vp1;        // normal, dot(wo, n)
+    const float4* vp3;        // R / pi of the surface
+    float* phi;               // 3 planes over the visible points
+    int32_t* m;               // photons that reached each visible point
+    int64_t n_vis;
+    uint32_t buckets;
+};
+TKD uint32_t hg_hash(int x, int y, int z, uint32_t buckets) {      // src/TkSPPM.cpp:109-112
+    const int32_t h = (int32_t)(((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349663u) ^ ((uint32_t)z * 83492791u));
+    return (uint32_t)((unsigned long long)(long long)h % (unsigned long long)buckets);   // s32 widened to size_t, as there
+}
+TKD bool hg_world_to_grid(const HashGridParams& g, F3 p, int pi[3]) {   // src/TkSPPM.cpp:88-99, Bounds3::Offset
+    float o[3] = {p.x - g.bmin[0], p.y - g.bmin[1], p.z - g.bmin[2]};
+    bool in = true;
+    for (int i = 0; i < 3; ++i) {
+        if (g.bmax[i] > g.bmin[i]) o[i] /= g.bmax[i] - g.bmin[i];
+        pi[i] = (int)((float)g.res[i] * o[i]);
+        in = in && pi[i] >= 0 && pi[i] < g.res[i];
+        pi[i] = pi[i] < 0 ? 0 : (pi[i] > g.res[i] - 1 ? g.res[i] - 1 : pi[i]);
+    }
+    return in;
+}
+// A photon of power `w` arriving at x from direction wo: every visible point of x's cell within its
+// radius counts it and takes f * w (src/TkSPPM.cpp:211-233).
+TKD void hg_deposit(const HashGridView& g, F3 x, F3 wo, F3 w) {
+    const HashGridParams P = *g.prm;
+    if (!P.valid) return;
+    int pi[3];
+    if (!hg_world_to_grid(P, x, pi)) return;
+    const uint32_t b = hg_hash(pi[0], pi[1], pi[2], g.buckets);
+    const int e1 = g.start[b + 1];
+    for (int e = g.start[b]; e < e1; ++e) {
+        const int v = g.items[e];
+        const float4 vp = g.vp0[v];
+        const F3 d = sub3(mk3(vp.x, vp.y, vp.z), x);
+        if (dot3(d, d) <= vp.w * vp.w) {
+            atomicAdd(&g.m[v], 1);
+            const float4 vn = g.vp1[v];
+            if (vn.w * dot3(wo, mk3(vn.x, vn.y, vn.z)) > 0) {       // DiffuseMaterial::f
+                const float4 r = g.vp3[v];
+                atomicAdd(&g.phi[v], r.x * w.x);
+                atomicAdd(&g.phi[g.n_vis + v], r.y * w.y);
+                atomicAdd(&g.phi[2 * g.n_vis + v], r.z * w.z);
+            }
+        }
+    }
+}
+
 struct PhotonArgs {
     DScene sc;
+    HashGridView hg;     // KIND 2 only
     PathQueue q;
     int32_t* rec_count;
     float4* stage_pos;   // xyz + direction bits
@@ -231,7 +298,9 @@ TKD bool photon_on_hit(const PhotonArgs& a, int slot, int bounce, PhotonPath& P,
     const TkMaterial m = sc.mats[sp.mat];
     bool diffuse = m.type == TK_DIFFUSE;
     *specular = !diffuse;
-    if (KIND == 0) {
+    if (KIND == 2) {
+        if (bounce > 0) hg_deposit(a.hg, sp.p, wo, P.power);
+    } else if (KIND == 0) {
         if (diffuse) {
             int c = P.flags;   // photons this path has staged so far
             int64_t at = (int64_t)slot * a.slots + c;
@@ -424,6 +493,8 @@ struct CameraArgs {
     uint32_t seed;
     int no_jitter;
     int caustic_stored;
+    int visible_only;    // hash-grid variant: the path ends at its first diffuse hit, which becomes the pixel's visible point
+    float ld_scale;      // 1 / spp there (src/TkSPPM.cpp:160-161), 1 otherwise
     float4* gq;          // global queries: 4 arrays of capacity n_slots, back to back
     float4* cq;          // caustic queries
     int64_t qcap;
@@ -477,6 +548,7 @@ TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp
 
 TKD void add_direct(const CameraArgs& a, int pixel, F3 Ld) {
     if (!isblack(Ld)) {
+        Ld = scale3(Ld, a.ld_scale);   // a power of two: exact
         a.planes[pixel] += Ld.x;
         a.planes[a.n_pixels + pixel] += Ld.y;
         a.planes[2 * a.n_pixels + pixel] += Ld.z;
@@ -546,8 +618,11 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
     bool go_on = true;
     if (diffuse) {
         out.sp = sp; out.coef = coef; out.m = m;
-        if (has_glossy && a.caustic_stored > 0) out.want_cq = true;
-        if (!has_glossy) { out.want_gq = true; go_on = false; }
+        if (a.visible_only) { out.want_cq = true; go_on = false; }   // src/TkSPPM.cpp:162-167
+        else {
+            if (has_glossy && a.caustic_stored > 0) out.want_cq = true;
+            if (!has_glossy) { out.want_gq = true; go_on = false; }
+        }
     }
     F3 n_o = P.o, n_d = P.d, n_coef = coef;
     int n_flags = P.flags;
@@ -765,6 +840,8 @@ void destroy_sppm(tkhip_ctx* ctx) {
     s->planes.release();
     s->rows.release();
     s->preview.release();
+    for (DevBuf* b : {&s->hg_prm, &s->hg_bounds, &s->hg_count, &s->hg_start, &s->hg_cursor, &s->hg_items, &s->hg_phi, &s->hg_m})
+        b->release();
     if (s->lane[0].stream) {
         hipStream_t three[3] = {s->lane[0].stream, s->lane[1].stream, s->lane[2].stream};
         for (hipStream_t st : three) (void)hipStreamSynchronize(st);
@@ -944,6 +1021,8 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.seed = s->seed;
     a.no_jitter = s->no_jitter;
     a.caustic_stored = expect_caustic ? 1 : 0;
+    a.visible_only = s->hashgrid ? 1 : 0;
+    a.ld_scale = s->hashgrid ? 1.0f / (float)s->hg_spp : 1.0f;
     a.gq = s->qbuf[0].as<float4>();
     a.cq = s->qbuf[1].as<float4>();
     a.qcap = s->n_slots;
@@ -1146,6 +1225,120 @@ static int sppm_begin_launches(tkhip_ctx* ctx, SppmState* s, const std::vector<i
     for (Lane& l : s->lane) TK_HIP(hipStreamSynchronize(l.stream));
     return TKHIP_OK;
 }
+
+namespace tkd {
+// ------------------------------------------------ hash-grid SPPM (src/TkSPPM.cpp)
+TKD uint32_t hg_f2ord(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+TKD float hg_ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+// Bounds of the search boxes of the visible points and their largest radius (src/TkSPPM.cpp:49-62).
+// bounds[0..2] min, [3..5] max, [6] largest radius, all as order-preserving integers.
+__global__ void k_hg_bounds(const float4* vp0, int64_t n, uint32_t* bounds) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, r = -INFINITY;
+    if (i < n) {
+        const float4 v = vp0[i];
+        lo[0] = v.x - v.w; lo[1] = v.y - v.w; lo[2] = v.z - v.w;
+        hi[0] = v.x + v.w; hi[1] = v.y + v.w; hi[2] = v.z + v.w;
+        r = v.w;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+        r = fmaxf(r, __shfl_xor(r, off));
+    }
+    if ((threadIdx.x & 63) == 0 && r > -INFINITY) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bounds[a], hg_f2ord(lo[a]));
+            atomicMax(&bounds[3 + a], hg_f2ord(hi[a]));
+        }
+        atomicMax(&bounds[6], hg_f2ord(r));
+    }
+}
+// Grid resolution (src/TkSPPM.cpp:64-68).
+__global__ void k_hg_setup(const uint32_t* bounds, int64_t n, HashGridParams* out) {
+    HashGridParams g;
+    g.valid = n > 0 ? 1 : 0;
+    float diag[3];
+    for (int a = 0; a < 3; ++a) {
+        g.bmin[a] = n > 0 ? hg_ord2f(bounds[a]) : 0.f;
+        g.bmax[a] = n > 0 ? hg_ord2f(bounds[3 + a]) : 0.f;
+        diag[a] = g.bmax[a] - g.bmin[a];
+        g.res[a] = 1;
+    }
+    if (n > 0) {
+        const float max_radius = hg_ord2f(bounds[6]);
+        const int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);   // Bounds3::maxExtent
+        const float max_diag = diag[ext];
+        const int base = (int)(max_diag / max_radius);
+        for (int a = 0; a < 3; ++a) {
+            const int r = (int)((float)base * diag[a] / max_diag);
+            g.res[a] = r > 1 ? r : 1;
+        }
+    }
+    *out = g;
+}
+// Every visible point into all the cells its search box overlaps (src/TkSPPM.cpp:70-85): FILL = false
+// counts per bucket, FILL = true writes the lists.
+template <bool FILL>
+__global__ void k_hg_insert(const float4* vp0, int64_t n, const HashGridParams* prm, uint32_t buckets, int32_t* count,
+                            const int32_t* start, int32_t* items) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const HashGridParams g = *prm;
+    const float4 v = vp0[i];
+    int lo[3], hi[3];
+    hg_world_to_grid(g, mk3(v.x - v.w, v.y - v.w, v.z - v.w), lo);
+    hg_world_to_grid(g, mk3(v.x + v.w, v.y + v.w, v.z + v.w), hi);
+    for (int z = lo[2]; z <= hi[2]; ++z)
+        for (int y = lo[1]; y <= hi[1]; ++y)
+            for (int x = lo[0]; x <= hi[0]; ++x) {
+                const uint32_t b = hg_hash(x, y, z, buckets);
+                const int at = atomicAdd(&count[b], 1);
+                if (FILL) items[start[b] + at] = (int)i;
+            }
+}
+// updatePixel (src/TkSPPM.cpp:252-272) for the pixels that have a visible point this iteration.
+// Planes: 3..5 Tau, 9 N, 11 radius.
+__global__ void k_hg_update(const float4* vp2, const float* phi, const int32_t* m, int64_t n, float* planes, int64_t np) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int M = m[i];
+    if (M <= 0) return;
+    const float4 t = vp2[i];   // throughput, pixel
+    const int64_t px = __float_as_int(t.w);
+    const float alpha = 0.7f;
+    const float N = planes[9 * np + px], radius = planes[11 * np + px];
+    const float newN = N + alpha * (float)M;
+    const float newR = radius * sqrtf(newN / (N + (float)M));
+    const float thr[3] = {t.x, t.y, t.z};
+    for (int c = 0; c < 3; ++c) {
+        const float tau = planes[(3 + c) * np + px];
+        planes[(3 + c) * np + px] = (tau + thr[c] * phi[c * n + i]) * (newR * newR) / (radius * radius);
+    }
+    planes[9 * np + px] = newN;
+    planes[11 * np + px] = newR;
+}
+// The final image (src/TkSPPM.cpp:436-450), rows bottom-up.
+__global__ void k_hg_resolve(const float* planes, int64_t np, int W, int H, int iterations, int photons_per_it, uint8_t* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const int x = (int)(i % W), y = (int)(i / W);
+    const float radius = planes[11 * np + i];
+    const float denom = (float)(iterations * photons_per_it) * kPi * radius * radius;
+    uint8_t* o = out + ((int64_t)(H - 1 - y) * W + x) * 3;
+    for (int c = 0; c < 3; ++c) {
+        const float v = planes[c * np + i] / (float)iterations + planes[(3 + c) * np + i] / denom;
+        const float cl = sse_max(sse_min(v, 1.0f), 0.0f);
+        o[c] = (uint8_t)(255 * powf(cl, 0.6f));
+    }
+}
+}  // namespace tkd
 
 namespace tkd {
 int sppm_local_photons(tkhip_ctx* ctx, int which, const void** pos, const void** pow, const void** dir, int64_t* n,
@@ -1611,6 +1804,135 @@ int tkhip_sppm_read_photons(tkhip_ctx* ctx, int which, float* pos, float* power,
         if (phi) TK_HIP(hipMemcpyAsync(phi, d + cnt, (size_t)cnt, hipMemcpyDeviceToHost, st));
     }
     TK_HIP(hipStreamSynchronize(st));
+    return TKHIP_OK;
+}
+
+/* ---- hash-grid variant ---- */
+int tkhip_hsppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int spp, int max_depth, float rr, uint64_t seed) {
+    TK_REQUIRE(ctx && param, TKHIP_E_ARG, "tkhip_hsppm_begin: null argument");
+    TK_REQUIRE(spp >= 1 && (spp & (spp - 1)) == 0, TKHIP_E_ARG, "tkhip_hsppm_begin: spp must be a power of two (RayTracer rounds it up)");
+    TK_REQUIRE(param->radius2 > 0.f, TKHIP_E_ARG, "tkhip_hsppm_begin: the initial radius must be positive");
+    TkSppmParam p = *param;
+    p.causticSize = 0;                 // one photon budget per iteration (photonsPerIt = globalSize)
+    TK_TRY(tkhip_sppm_begin(ctx, &p, max_depth, rr, seed, 0, 1));
+    SppmState* s = ctx->sppm;
+    s->hashgrid = true;
+    s->hg_spp = spp;
+    TK_TRY(s->hg_prm.ensure(sizeof(HashGridParams)));
+    TK_TRY(s->hg_bounds.ensure(8 * 4));
+    TK_TRY(s->hg_count.ensure((size_t)(s->n_pixels + 1) * 4));
+    TK_TRY(s->hg_start.ensure((size_t)(s->n_pixels + 1) * 4));
+    return TKHIP_OK;
+}
+
+int tkhip_hsppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_hsppm_iteration");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->hashgrid, TKHIP_E_STATE, "tkhip_hsppm_iteration: the render was not begun with tkhip_hsppm_begin");
+    const double t0 = now_ms();
+    if (st) memset(st, 0, sizeof(*st));
+    // ray pass: the visible point of every pixel (src/TkSPPM.cpp:136-179)
+    TK_TRY(camera_trace(ctx, iter, true));
+    if (st) {
+        TK_TRY(collect_rays(ctx, 2, st));
+        st->ms_camera = (float)(now_ms() - t0);
+    }
+    const int64_t nv = s->n_queries[1];
+    const uint32_t buckets = (uint32_t)s->n_pixels;
+    hipStream_t stream = ctx->stream;
+    const float4* q = s->qbuf[1].as<float4>();
+    const float4 *vp0 = q, *vp1 = q + s->n_slots, *vp2 = q + 2 * s->n_slots, *vp3 = q + 3 * s->n_slots;
+    // grid rebuild (src/TkSPPM.cpp:45-86)
+    const double t1 = now_ms();
+    const uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    TK_HIP(hipMemcpyAsync(s->hg_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    TK_HIP(hipMemsetAsync(s->hg_count.p, 0, (size_t)(buckets + 1) * 4, stream));
+    if (nv > 0) {
+        k_hg_bounds<<<divup(nv, 256), 256, 0, stream>>>(vp0, nv, s->hg_bounds.as<uint32_t>());
+        TK_LAUNCH_CHECK();
+    }
+    k_hg_setup<<<1, 1, 0, stream>>>(s->hg_bounds.as<uint32_t>(), nv, s->hg_prm.as<HashGridParams>());
+    TK_LAUNCH_CHECK();
+    int32_t total = 0;
+    if (nv > 0) {
+        k_hg_insert<false><<<divup(nv, 256), 256, 0, stream>>>(vp0, nv, s->hg_prm.as<HashGridParams>(), buckets,
+                                                               s->hg_count.as<int32_t>(), nullptr, nullptr);
+        TK_LAUNCH_CHECK();
+    }
+    TK_TRY(exclusive_scan_i32(stream, ctx->prim_temp, s->hg_count.as<int32_t>(), s->hg_start.as<int32_t>(), (size_t)buckets + 1));
+    TK_HIP(hipMemcpyAsync(&total, s->hg_start.as<int32_t>() + buckets, 4, hipMemcpyDeviceToHost, stream));
+    TK_HIP(hipStreamSynchronize(stream));
+    TK_TRY(s->hg_items.ensure((size_t)std::max(total, 1) * 4));
+    TK_TRY(s->hg_phi.ensure((size_t)std::max<int64_t>(nv, 1) * 3 * 4));
+    TK_TRY(s->hg_m.ensure((size_t)std::max<int64_t>(nv, 1) * 4));
+    TK_HIP(hipMemsetAsync(s->hg_phi.p, 0, (size_t)std::max<int64_t>(nv, 1) * 3 * 4, stream));
+    TK_HIP(hipMemsetAsync(s->hg_m.p, 0, (size_t)std::max<int64_t>(nv, 1) * 4, stream));
+    if (nv > 0) {
+        TK_HIP(hipMemsetAsync(s->hg_count.p, 0, (size_t)(buckets + 1) * 4, stream));
+        k_hg_insert<true><<<divup(nv, 256), 256, 0, stream>>>(vp0, nv, s->hg_prm.as<HashGridParams>(), buckets,
+                                                              s->hg_count.as<int32_t>(), s->hg_start.as<int32_t>(),
+                                                              s->hg_items.as<int32_t>());
+        TK_LAUNCH_CHECK();
+    }
+    TK_HIP(hipStreamSynchronize(stream));
+    if (st) st->ms_build = (float)(now_ms() - t1);
+    // photon pass (src/TkSPPM.cpp:181-250): photonsPerIt light paths, Halton index iter * photonsPerIt + i
+    const double t2 = now_ms();
+    Lane& ln = s->lane[0];
+    const int64_t per_it = s->prm.globalSize;
+    int32_t* counters = ln.counters.as<int32_t>();
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, ln.stream));
+    for (int64_t done = 0; done < per_it;) {
+        const int64_t B = std::min<int64_t>(per_it - done, (int64_t)1 << 22);
+        PhotonArgs a{};
+        a.sc = ctx->scene;
+        TK_TRY(ln.q_o.ensure((size_t)B * 16));
+        TK_TRY(ln.q_d.ensure((size_t)B * 16));
+        TK_TRY(ln.q_w.ensure((size_t)B * 16));
+        a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)B};
+        a.hg = HashGridView{s->hg_prm.as<HashGridParams>(), s->hg_start.as<int32_t>(), s->hg_items.as<int32_t>(), vp0, vp1, vp3,
+                            s->hg_phi.as<float>(), s->hg_m.as<int32_t>(), nv, buckets};
+        a.m0 = done;
+        a.hoff = (int64_t)iter * per_it;
+        a.world = 1; a.rank = 0; a.seed = s->seed; a.rr = s->rr; a.slots = 1; a.depth = s->max_depth;
+        TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, ln.stream));
+        k_photon_first<2><<<divup(B, kTraceBlock), kTraceBlock, 0, ln.stream>>>(a, B, counters);
+        const int waves = (int)std::min<int64_t>(divup(B, kPathBlock), std::max(s->path_waves[0], 64));
+        k_photon_paths<2><<<waves, kPathBlock, 0, ln.stream>>>(a, counters);
+        TK_LAUNCH_CHECK();
+        done += B;
+    }
+    TK_HIP(hipStreamSynchronize(ln.stream));
+    s->shoot[0] += per_it;
+    if (st) {
+        TK_TRY(collect_rays(ctx, 0, st));
+        st->ms_photon = (float)(now_ms() - t2);
+        st->global_paths = per_it;
+        st->shoot_global = s->shoot[0];
+        st->gathers_caustic = nv;
+    }
+    // renew pass (src/TkSPPM.cpp:252-272)
+    if (nv > 0) {
+        k_hg_update<<<divup(nv, 256), 256, 0, stream>>>(vp2, s->hg_phi.as<float>(), s->hg_m.as<int32_t>(), nv, s->planes.as<float>(),
+                                                        s->n_pixels);
+        TK_LAUNCH_CHECK();
+    }
+    TK_HIP(hipStreamSynchronize(stream));
+    if (st) st->ms_total = (float)(now_ms() - t0);
+    return TKHIP_OK;
+}
+
+int tkhip_hsppm_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out) {
+    TK_CTX_SPPM(ctx, "tkhip_hsppm_resolve_rgb8");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->hashgrid && host_out, TKHIP_E_STATE, "tkhip_hsppm_resolve_rgb8: no hash-grid render, or null buffer");
+    const size_t bytes = (size_t)s->n_pixels * 3;
+    TK_TRY(ctx->scratch_a.ensure(bytes));
+    k_hg_resolve<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, ctx->cam.w, ctx->cam.h,
+                                                                  s->num_recurse, s->prm.globalSize, ctx->scratch_a.as<uint8_t>());
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(host_out, ctx->scratch_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
     return TKHIP_OK;
 }
 

@@ -96,9 +96,23 @@ public:
     const std::vector<TkIterStats>& stats() const { return mStats; }
 };
 
+// The reference's second SPPM class (src/TkSPPM.h:34-64): visible point per pixel, spatial hash
+// grid, photons deposited into the pixels they reach.  Same constructor, same three calls.
+class SPPM : public RayTracer {
+    TkSppmParam mParam;
+    int numIteration = 0;
+    int curIteration = 0;
+    void rendering() override;
+public:
+    SPPM(int spp, int maxDepth, int numThreads, float russianRoulette, TkSppmParam param);
+    void startRaytracing() override;
+    void saveImage(std::string filename = "") override;
+    void render(std::string filename) override;
+};
+
 // parse_tracer's dispatch on the type attribute (src/TkLoader.cpp:238-262).
-// Only "sppm" has a device path; the other integrators return null with a
-// message in *error.
+// "sppm" (tk::SppmTracer) and "sppm_hash" (tk::SPPM, chosen by <hashgrid i="1"/>) have a device path;
+// the other integrators return null with a message in *error.
 std::unique_ptr<RayTracer> createTracer(const TkTracerConfig& cfg, std::string* error);
 
 }  // namespace tk

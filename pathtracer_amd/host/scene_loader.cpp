@@ -406,6 +406,11 @@ void loadScene(Config* config, const std::string& filename) {
         childInt(tr, true, "csize", &tc.sppm.causticSize);
         childInt(tr, true, "csample", &tc.sppm.causticSample);
         childReal(tr, true, "radius", &tc.sppm.radius2);
+        // The reference chooses between its two SPPM classes by editing src/TkLoader.cpp:249-250; here
+        // <hashgrid i="1"/> inside the tracer block selects tk::SPPM (type "sppm_hash" from here on).
+        int hashgrid = 0;
+        childInt(tr, false, "hashgrid", &hashgrid);
+        if (hashgrid) snprintf(tc.type, sizeof(tc.type), "sppm_hash");
     }
 
     SceneData& sc = config->scene;

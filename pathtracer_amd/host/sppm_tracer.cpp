@@ -278,8 +278,68 @@ void SppmTracer::render(std::string filename) {
     if (mState == DONE) saveImage(filename);
 }
 
+// ------------------------------------------------------ hash-grid SPPM
+SPPM::SPPM(int spp, int maxDepth, int numThreads, float russianRoulette, TkSppmParam param)
+    : RayTracer(spp, maxDepth, numThreads, russianRoulette), mParam(param) {
+    int x = 0, y = 0;
+    while (++x * ++y < param.numRecurse) {}   // src/TkSPPM.cpp:120-122
+    numIteration = x * y;
+}
+
+void SPPM::startRaytracing() {   // src/TkSPPM.cpp:274-282
+    if (mState != READY) return;
+    curIteration = 0;
+    releaseDevice();
+    if (mGpus > 1) fprintf(stderr, "\r[Tracer] the hash-grid tracer renders on one GPU; --gpus ignored\n");
+    mGpus = 1;
+    if (!uploadScene()) return;
+    if (tkhip_hsppm_begin(mCtx, &mParam, mSpp, mMaxDepth, mRussianRoulette, mSeed) != 0) {
+        fail("tkhip_hsppm_begin");
+        return;
+    }
+    RayTracer::startRaytracing();
+}
+
+// One round of ray pass, photon pass and renew pass (the three states of src/TkSPPM.cpp:347-431).
+void SPPM::rendering() {
+    if (mState != RENDERING) return;
+    TkIterStats st;
+    if (tkhip_hsppm_iteration(mCtx, curIteration, &st) != 0) {
+        fail("tkhip_hsppm_iteration");
+        mState = READY;
+        return;
+    }
+    fprintf(stderr, "\r[Tracer] Iteration %d... Done!  (%.2f ms: ray pass %.2f, grid %.2f, photon pass %.2f; %lld visible points)\n",
+            curIteration, st.ms_total, st.ms_camera, st.ms_build, st.ms_photon, (long long)st.gathers_caustic);
+    if (++curIteration >= numIteration) {
+        fprintf(stderr, "\r[Tracer] Rendering Done!\n");
+        mState = DONE;
+    }
+}
+
+void SPPM::saveImage(std::string filename) {
+    if (mState != DONE && mState != RENDERING) return;
+    if (filename.empty()) filename = "binary.ppm";
+    std::vector<uint8_t> rgb(size_t(mWidth) * size_t(mHeight) * 3);
+    if (tkhip_hsppm_resolve_rgb8(mCtx, rgb.data()) != 0) {
+        fail("tkhip_hsppm_resolve_rgb8");
+        return;
+    }
+    fprintf(stderr, "\n[Tracer] Saving to file: %s... ", filename.c_str());
+    if (tkhost_write_ppm(filename.c_str(), mWidth, mHeight, rgb.data()) == 0) fprintf(stderr, "Done!\n");
+    else fprintf(stderr, "FAILED\n");
+}
+
+void SPPM::render(std::string filename) {   // src/TkSPPM.cpp:347-465
+    startRaytracing();
+    while (mState == RENDERING) rendering();
+    if (mState == DONE) saveImage(filename);
+}
+
 std::unique_ptr<RayTracer> createTracer(const TkTracerConfig& cfg, std::string* error) {
     std::string type = cfg.type;
+    if (type == "sppm_hash")
+        return std::unique_ptr<RayTracer>(new SPPM(cfg.spp, cfg.max_depth, cfg.num_threads, cfg.russian_roulette, cfg.sppm));
     if (type == "sppm")
         return std::unique_ptr<RayTracer>(
             new SppmTracer(cfg.spp, cfg.max_depth, cfg.num_threads, cfg.russian_roulette, cfg.sppm));

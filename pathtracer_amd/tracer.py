@@ -377,6 +377,43 @@ class SppmTracer:
             self.ctx = None
 
 
+class HashGridSppm:
+    """The hash-grid SPPM variant (tkhip_hsppm_*): visible point per pixel, photons deposited through a
+    spatial hash grid.  param.globalSize = light paths per iteration, param.radius2 = the initial radius."""
+
+    def __init__(self, scene, param, spp, max_depth, rr, width, height, device=0, seed=0x5EED):
+        self.ctx = Context(device)
+        self.ctx.set_scene(scene)
+        self.ctx.set_camera(scene, width, height)
+        self.width, self.height, self.param = width, height, param
+        lib = self.ctx.lib
+        check(lib, lib.tkhip_hsppm_begin(self.ctx.h, C.byref(param), spp, max_depth, rr, seed), "tkhip_hsppm_begin")
+        self.cur = 0
+
+    def iteration(self, it=None):
+        it = self.cur if it is None else it
+        st = _abi.TkIterStats()
+        check(self.ctx.lib, self.ctx.lib.tkhip_hsppm_iteration(self.ctx.h, it, C.byref(st)), "tkhip_hsppm_iteration")
+        self.cur = it + 1
+        return st
+
+    def pixels(self):
+        n = self.width * self.height
+        buf = (_abi.TkSPPMPixel * n)()
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_read_pixels(self.ctx.h, buf), "tkhip_sppm_read_pixels")
+        return np.frombuffer(buf, dtype=np.float32).reshape(n, 13).copy()
+
+    def resolve(self):
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        check(self.ctx.lib, self.ctx.lib.tkhip_hsppm_resolve_rgb8(self.ctx.h, _bp(out)), "tkhip_hsppm_resolve_rgb8")
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.ctx.close()
+            self.ctx = None
+
+
 class SppmGroup:
     """One SPPM render over several GPUs of this process (tkhip_group_*): one context and one host thread per
     rank inside the library, photons exchanged with peer copies.  `devices` may repeat a GPU."""
