@@ -342,6 +342,24 @@ int tkhip_hsppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* stats);
 /* Final image of SPPM::render (src/TkSPPM.cpp:436-450): RGB8, rows bottom-up. */
 int tkhip_hsppm_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out);
 
+/* ------------------------------------------------ path tracer: tk::PathTracer
+ * <tracer type="pt"> of the reference (src/tracer/TkPathTracer.cpp): spp samples
+ * per pixel from a stratified sampler of x * y strata (ctor, :13-24), each a
+ * path with next-event estimation at every hit, emitted light seen on the
+ * first hit and after specular bounces, Russian roulette (Li, :149-204), summed
+ * into the film of the headless program: box filter of radius 0.5
+ * (src/main.cpp:41, FilmTile::addSample, src/core/TkFilm.cpp:14-42), i.e. a
+ * sample counts for its own pixel and, when it sits exactly on a pixel edge,
+ * for the neighbour as well.  The reference renders tile by tile, all samples
+ * of a tile at once (traceTile, :127-147); here a call renders the next
+ * `count` samples of EVERY pixel, so an image can be shown after any call.
+ * spp is RayTracer's (a power of two).  tkhip_sppm_read_pixels then reports
+ * Ld = Pixel::contribSum and causticPhotons = Pixel::filterWeightSum. */
+int tkhip_pt_begin(tkhip_ctx* ctx, int spp, int max_depth, float russian_roulette, uint64_t seed);
+int tkhip_pt_render_samples(tkhip_ctx* ctx, int count, TkIterStats* stats);
+/* Film::writeImage (src/core/TkFilm.cpp:124-153): RGB8, rows bottom-up. */
+int tkhip_pt_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out);
+
 /* ------------------------------------------------ several GPUs, one process
  * The reference spreads an iteration over the threads of one machine (TkSpawn /
  * TkWait, src/Threads.cpp:19-56, called from src/tracer/TkSppmTracer.cpp:411-438

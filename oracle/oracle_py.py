@@ -72,6 +72,8 @@ def lib():
         "orc_sppm_resolve": (None, [C.c_void_p, u8p]),
         "orc_hsppm_iteration": (None, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
         "orc_hsppm_resolve": (None, [C.c_void_p, u8p]),
+        "orc_pt_render": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p]),
+        "orc_pt_resolve": (None, [f32p, f32p, C.c_int, C.c_int, u8p]),
         "orc_sppm_read_photons": (C.c_int64, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, i64p]),
         "orc_sppm_set_map_photons": (None, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, C.c_int64, C.c_int64]),
         "orc_sppm_counters": (None, [C.c_void_p, i64p, i64p, i32p]),
@@ -239,6 +241,15 @@ class OracleSppm:
         st = (C.c_int64 * 3)()
         lib().orc_hsppm_iteration(self.h, spp, it, st)
         return list(st)
+
+    # path tracer on this state's scene / depth / roulette / seed
+    def pt_render(self, spp, s0, s1, contrib, wsum):
+        lib().orc_pt_render(self.h, spp, s0, s1, fp(contrib), fp(wsum))
+
+    def pt_resolve(self, contrib, wsum):
+        out = np.empty((self.oscene.height, self.oscene.width, 3), np.uint8)
+        lib().orc_pt_resolve(fp(contrib), fp(wsum), self.oscene.width, self.oscene.height, bp(out))
+        return out
 
     def hash_resolve(self):
         out = np.empty((self.oscene.height, self.oscene.width, 3), np.uint8)

@@ -2047,3 +2047,109 @@ void orc_hsppm_resolve(orc_sppm* r, uint8_t* out) {
             }
         }
 }
+
+/* ===================================================================== path tracer
+ * PathTracer (src/tracer/TkPathTracer.cpp:13-24, :127-204) with the film of the headless program:
+ * BoxFilter(0.5, 0.5) (src/main.cpp:41), FilmTile::addSample / Film::mergeFilmTile / Film::writeImage
+ * (src/core/TkFilm.cpp:14-42, :108-153), FilterTable (src/core/TkFilter.cpp:13-32).  The Russian
+ * roulette draw (get_random_float, unseeded in the reference) is the hashed number the GPU uses.
+ * Samples are added to the film pixel by pixel in sample order (the reference adds them tile by
+ * tile; the sums differ in the last bits only when a sample lands on a pixel edge).
+ * Uses the scene, depth, roulette probability and seed of an orc_sppm. */
+static v3 pt_li(const orc_sppm* r, Ray ray, Sampler* sm, int pixel, int sample, TraceCounters* tc) {
+    const orc_scene* s = r->sc;
+    v3 L = V(0, 0, 0), beta = V(1, 1, 1);
+    int test = 1;
+    for (int bounces = 0; bounces < r->max_depth; ++bounces) {
+        Isect is; memset(&is, 0, sizeof(is));
+        if (!scene_intersect(s, &ray, &is, r->faithful, tc)) break;
+        v3 wo = vneg(ray.d);
+        const TkObject* ob = &s->objects[is.obj];
+        const TkMaterial* m = &s->mats[ob->material];
+        /* the GPU adds the two terms of a hit as one sum to the film; same grouping here */
+        v3 here = V(0, 0, 0);
+        if (test && ob->light >= 0) here = vadd(here, vmul(beta, light_L(&s->lights[ob->light], is.n, wo)));
+        here = vadd(here, vmul(beta, uniform_sample_one_light(r, &is, sm, tc)));
+        L = vadd(L, here);
+        if (orc_rng_u01(r->seed, (uint32_t)pixel, (uint32_t)sample, 0x10000u + (uint32_t)bounces) > r->rr) break;
+        v3 wi; float pdf;
+        float ux, uy;
+        sampler_get2d(sm, &ux, &uy);
+        v3 f = mat_sample_f(m, 0, wo, &wi, is.n, ux, uy, &pdf);
+        if (pdf == 0 || (f.x == 0 && f.y == 0 && f.z == 0)) break;
+        test = (m->type & (TK_GLASS | TK_MIRROR)) != 0;
+        beta = vmul(beta, vdivs(vscale(f, vabsdot(wi, is.n)), pdf * r->rr));
+        ray = spawn_ray(&is, wi);
+    }
+    return L;
+}
+
+typedef struct { orc_sppm* r; int spp, xs, ys, s0, s1; float* contrib; float* wsum; pthread_mutex_t* mu; TraceCounters* tcs; } PtJob;
+static void pt_row_job(void* a, int64_t yy, int tid) {
+    PtJob* j = (PtJob*)a;
+    orc_sppm* r = j->r;
+    const orc_scene* s = r->sc;
+    const int W = s->w, H = s->h, y = (int)yy;
+    /* FilterTable of the box filter: every entry 1 / normalizeTerm = 1 / (4 * 0.5 * 0.5) */
+    const float weight = 1.0f * (1.0f / (4.0f * 0.5f * 0.5f));
+    for (int x = 0; x < W; ++x) {
+        for (int k = j->s0; k < j->s1; ++k) {
+            Sampler sm;
+            sm.px = x; sm.py = y; sm.sample_idx = k; sm.spp = j->spp; sm.xs = j->xs; sm.ys = j->ys; sm.dim = 0; sm.seed = 0;
+            sm.rng_seed = r->seed; sm.rng_pixel = (uint32_t)(x + y * W); sm.rng_iter = (uint32_t)k; sm.rng_cost = r->rng_cost; sm.no_jitter = r->no_jitter;
+            float cx, cy, lx, ly;
+            sampler_get2d(&sm, &cx, &cy);
+            cx = cx + (float)x; cy = cy + (float)y;
+            sampler_get2d(&sm, &lx, &ly);
+            Ray ray = camera_ray(s, cx, cy);
+            v3 L = pt_li(r, ray, &sm, x + y * W, k, &j->tcs[tid]);
+            /* FilmTile::addSample */
+            float dx = cx - 0.5f, dy = cy - 0.5f;
+            int p0x = (int)ceilf(dx - 0.5f), p0y = (int)ceilf(dy - 0.5f);
+            int p1x = (int)floorf(dx + 0.5f + 1), p1y = (int)floorf(dy + 0.5f + 1);
+            if (p0x < 0) p0x = 0;
+            if (p0y < 0) p0y = 0;
+            if (p1x > W) p1x = W;
+            if (p1y > H) p1y = H;
+            int own = p0x == x && p1x == x + 1 && p0y == y && p1y == y + 1;
+            if (!own) pthread_mutex_lock(j->mu);   /* a neighbour's row may be another thread's */
+            for (int py = p0y; py < p1y; ++py)
+                for (int px = p0x; px < p1x; ++px) {
+                    float* c = &j->contrib[3 * (px + py * W)];
+                    c[0] += L.x * weight; c[1] += L.y * weight; c[2] += L.z * weight;
+                    j->wsum[px + py * W] += weight;
+                }
+            if (!own) pthread_mutex_unlock(j->mu);
+        }
+    }
+}
+/* Samples [s0, s1) of every pixel into the film (contrib: 3 floats per pixel, wsum: 1). */
+void orc_pt_render(orc_sppm* r, int spp, int s0, int s1, float* contrib, float* wsum) {
+    int T = r->threads < 1 ? 1 : (r->threads > 256 ? 256 : r->threads);
+    int x = 1, y = spp / x;                                  /* src/tracer/TkPathTracer.cpp:16-22 */
+    while (y != x && y / x != 2) { x <<= 1; y = spp / x; }
+    pthread_mutex_t mu;
+    pthread_mutex_init(&mu, 0);
+    TraceCounters* tcs = (TraceCounters*)calloc((size_t)T, sizeof(TraceCounters));
+    PtJob job = {r, spp, x, y, s0, s1, contrib, wsum, &mu, tcs};
+    /* rows that share an edge sample are serialised by the mutex; a row's own sums are only ever
+     * touched by the thread that has the row, except for those edge samples */
+    parallel_for(T, r->sc->h, 1, pt_row_job, &job);
+    for (int t = 0; t < T; ++t) { r->tc_camera[0] += tcs[t].rays; r->tc_camera[1] += tcs[t].nodes; r->tc_camera[2] += tcs[t].prims; }
+    free(tcs);
+    pthread_mutex_destroy(&mu);
+}
+/* Film::writeImage, src/core/TkFilm.cpp:124-153 (square images: its x loop runs over the y bounds). */
+void orc_pt_resolve(const float* contrib, const float* wsum, int w, int h, uint8_t* out) {
+    int off = 0;
+    for (int y = h; y-- > 0;)
+        for (int x = 0; x < w; ++x) {
+            int idx = x + y * w;
+            for (int c = 0; c < 3; ++c) {
+                float v = contrib[3 * idx + c];
+                if (wsum[idx] != 0) v = v / wsum[idx];
+                float cl = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                out[off++] = (uint8_t)(255 * powf(cl, 0.6f));
+            }
+        }
+}

@@ -138,6 +138,12 @@ int orc_sppm_camera_path(orc_sppm* r, int iter, int x, int y, float ld_out[3], O
 void orc_hsppm_iteration(orc_sppm* r, int spp, int iter, int64_t stats[3]);
 void orc_hsppm_resolve(orc_sppm* r, uint8_t* out);
 
+/* --- path tracer, PathTracer::Li + the headless program's film (box filter of radius 0.5) on the
+ * scene, depth, roulette probability and seed of an orc_sppm.  contrib: 3 floats per pixel,
+ * wsum: 1 (Pixel::contribSum / filterWeightSum); samples [s0, s1) of spp. */
+void orc_pt_render(orc_sppm* r, int spp, int s0, int s1, float* contrib, float* wsum);
+void orc_pt_resolve(const float* contrib, const float* wsum, int w, int h, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,9 @@ TKHIP_SYMBOLS = {
     "tkhip_hsppm_begin": (C.c_int, [C.c_void_p, C.POINTER(TkSppmParam), C.c_int, C.c_int, C.c_float, C.c_uint64]),
     "tkhip_hsppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_hsppm_resolve_rgb8": (C.c_int, [C.c_void_p, c_uint8_p]),
+    "tkhip_pt_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64]),
+    "tkhip_pt_render_samples": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
+    "tkhip_pt_resolve_rgb8": (C.c_int, [C.c_void_p, c_uint8_p]),
     "tkhip_device_count": (C.c_int, []),
     "tkhip_group_create": (C.c_int, [c_int32_p, C.c_int, C.POINTER(C.c_void_p)]),
     "tkhip_group_destroy": (None, [C.c_void_p]),

@@ -142,6 +142,8 @@ struct SppmState {
     int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
     DevBuf qbuf[2];
     int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
+    bool pt_mode = false;            // path tracer (tkhip_pt_*): the pixel planes are the film
+    int pt_next_sample = 0;
     // hash-grid variant (tkhip_hsppm_*)
     bool hashgrid = false;
     int hg_spp = 1;
@@ -495,6 +497,8 @@ struct CameraArgs {
     int caustic_stored;
     int visible_only;    // hash-grid variant: the path ends at its first diffuse hit, which becomes the pixel's visible point
     float ld_scale;      // 1 / spp there (src/TkSPPM.cpp:160-161), 1 otherwise
+    int pt_mode;         // PathTracer::Li (src/tracer/TkPathTracer.cpp:149-204): no gathers, Russian roulette, film sums
+    float rr;
     float4* gq;          // global queries: 4 arrays of capacity n_slots, back to back
     float4* cq;          // caustic queries
     int64_t qcap;
@@ -536,6 +540,28 @@ TKD void camera_start(const CameraArgs& a, int x, int y, CameraPath& P) {
     P.coef = mk3(1.f, 1.f, 1.f);
     P.flags = 1 | (sm.dim << 1);
     P.shadow = false;
+    if (a.pt_mode) {
+        // FilmTile::addSample with the box filter of radius 0.5 (src/core/TkFilm.cpp:14-42, src/main.cpp:41):
+        // the pixels [p0, p1) the sample lands in are its own and, when the sample sits exactly on
+        // a pixel edge, a neighbour.  Bits 27..30 of the flags name the neighbours that also take it.
+        const float dx = cx - 0.5f, dy = cy - 0.5f;
+        const int p0x = (int)ceilf(dx - 0.5f), p1x = (int)floorf(dx + 0.5f + 1);
+        const int p0y = (int)ceilf(dy - 0.5f), p1y = (int)floorf(dy + 0.5f + 1);
+        if (p0x < x && x - 1 >= 0) P.flags |= 1 << 27;
+        if (p1x > x + 1 && x + 1 < a.cam.w) P.flags |= 1 << 28;
+        if (p0y < y && y - 1 >= 0) P.flags |= 1 << 29;
+        if (p1y > y + 1 && y + 1 < a.cam.h) P.flags |= 1 << 30;
+    }
+}
+constexpr int kPtFootprintMask = 0xf << 27;
+// Calls fn(pixel) for every pixel a path-tracer sample lands in.
+template <class F>
+TKD void pt_footprint(const CameraArgs& a, int pixel, int flags, F fn) {
+    const int W = a.cam.w;
+    const int xlo = (flags >> 27) & 1 ? -1 : 0, xhi = (flags >> 28) & 1 ? 1 : 0;
+    const int ylo = (flags >> 29) & 1 ? -1 : 0, yhi = (flags >> 30) & 1 ? 1 : 0;
+    for (int dy = ylo; dy <= yhi; ++dy)
+        for (int dx = xlo; dx <= xhi; ++dx) fn(pixel + dx + dy * W);
 }
 
 TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp, F3 coef, const TkMaterial& m,
@@ -546,7 +572,16 @@ TKD void emit_query(float4* qbase, int64_t qcap, int dst, const SurfacePoint& sp
     qbase[3 * qcap + dst] = make_float4(m.R[0] * kInvPi, m.R[1] * kInvPi, m.R[2] * kInvPi, 0.f);
 }
 
-TKD void add_direct(const CameraArgs& a, int pixel, F3 Ld) {
+TKD void add_direct(const CameraArgs& a, int pixel, F3 Ld, int flags = 0) {
+    if (a.pt_mode) {   // Pixel::contribSum (filter weight 1); a neighbour's sample may land here too: atomics
+        if (isblack(Ld)) return;
+        pt_footprint(a, pixel, flags, [&](int px) {
+            atomicAdd(&a.planes[px], Ld.x);
+            atomicAdd(&a.planes[a.n_pixels + px], Ld.y);
+            atomicAdd(&a.planes[2 * a.n_pixels + px], Ld.z);
+        });
+        return;
+    }
     if (!isblack(Ld)) {
         Ld = scale3(Ld, a.ld_scale);   // a power of two: exact
         a.planes[pixel] += Ld.x;
@@ -570,7 +605,8 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
                        CameraStepOut& out) {
     const DScene& sc = a.sc;
     bool has_glossy = P.flags & 1;
-    Sampler sm = make_sampler(a, x, y, P.flags >> 1);
+    const bool pt = a.pt_mode != 0;
+    Sampler sm = make_sampler(a, x, y, (P.flags & ~kPtFootprintMask) >> 1);
     const SurfacePoint sp = surface_at(sc, h, P.o, P.d);
     const TkMaterial m = sc.mats[sp.mat];
     const bool diffuse = m.type == TK_DIFFUSE;
@@ -580,7 +616,7 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
     if (has_glossy && sp.light >= 0) Ld = add3(Ld, mul3(coef, light_L(sc.lights[sp.light], sp.n, wo)));
     bool want_shadow = false;
     F3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 0), ld_light = mk3(0, 0, 0);
-    if ((has_glossy || !diffuse) && sc.n_lights > 0) {
+    if ((pt || has_glossy || !diffuse) && sc.n_lights > 0) {
         // uniformSampleOneLight: the sampler dimensions advance for every material
         int nl = sc.n_lights;
         int li = (int)(sampler_get1d(sm) * nl);
@@ -616,7 +652,9 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
     }
     // what follows the light sample does not depend on the shadow ray's answer
     bool go_on = true;
-    if (diffuse) {
+    if (pt) {   // Russian roulette before the BSDF sample (src/tracer/TkPathTracer.cpp:165-166)
+        if (rng_u01(a.seed, (uint32_t)pixel, (uint32_t)a.iter, 0x10000u + (uint32_t)bounce) > a.rr) go_on = false;
+    } else if (diffuse) {
         out.sp = sp; out.coef = coef; out.m = m;
         if (a.visible_only) { out.want_cq = true; go_on = false; }   // src/TkSPPM.cpp:162-167
         else {
@@ -627,7 +665,7 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
     F3 n_o = P.o, n_d = P.d, n_coef = coef;
     int n_flags = P.flags;
     if (go_on) {
-        has_glossy = has_glossy && !diffuse;
+        has_glossy = pt ? !diffuse : (has_glossy && !diffuse);   // pt: `test`, set by the surface just left (:172)
         float ux, uy;
         sampler_get2d(sm, &ux, &uy);
         F3 wi;
@@ -635,10 +673,11 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
         F3 f = mat_sample_f(m, false, wo, &wi, sp.n, ux, uy, &pdf);
         if (isblack(f) || pdf == 0 || !(bounce + 1 < a.depth)) go_on = false;
         else {
-            n_coef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
+            if (pt) n_coef = mul3(coef, divs3(scale3(f, absdot3(wi, sp.n)), pdf * a.rr));   // beta *= f * |cos| / (pdf * rr)
+            else n_coef = divs3(scale3(mul3(coef, f), absdot3(wi, sp.n)), pdf);
             n_o = offset_ray_origin(sp.p, sp.perr, sp.n, wi);
             n_d = wi;
-            n_flags = (has_glossy ? 1 : 0) | (sm.dim << 1);
+            n_flags = (has_glossy ? 1 : 0) | (sm.dim << 1) | (P.flags & kPtFootprintMask);
         }
     }
     if (want_shadow) {
@@ -647,7 +686,7 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
         P.o = sh_o; P.d = sh_d; P.shadow = true;
         return true;
     }
-    add_direct(a, pixel, Ld);
+    add_direct(a, pixel, Ld, P.flags);
     P.o = n_o; P.d = n_d; P.coef = n_coef; P.flags = n_flags;
     return go_on;
 }
@@ -665,7 +704,7 @@ TKD bool camera_after_ray(const CameraArgs& a, int x, int y, int pixel, int& bou
     if (P.shadow) {
         F3 Ld = P.ld_seen;
         if (h.prim < 0) Ld = add3(Ld, P.ld_light);
-        add_direct(a, pixel, Ld);
+        add_direct(a, pixel, Ld, P.flags);
         P.o = P.next_o; P.d = P.next_d; P.coef = P.next_coef; P.flags = P.next_flags;
         P.shadow = false;
         ++bounce;
@@ -701,6 +740,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int6
         y = a.rows[slot / W]; x = (int)(slot % W);
         pixel = x + y * W;
         camera_start(a, x, y, P);
+        if (a.pt_mode)   // Pixel::filterWeightSum
+            pt_footprint(a, pixel, P.flags, [&](int px) { atomicAdd(&a.planes[9 * a.n_pixels + px], 1.0f); });
         nrays = 1;
         alive = camera_turn(a, x, y, pixel, bounce, P, so, stk);
     }
@@ -1023,6 +1064,8 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.caustic_stored = expect_caustic ? 1 : 0;
     a.visible_only = s->hashgrid ? 1 : 0;
     a.ld_scale = s->hashgrid ? 1.0f / (float)s->hg_spp : 1.0f;
+    a.pt_mode = s->pt_mode ? 1 : 0;
+    a.rr = s->rr;
     a.gq = s->qbuf[0].as<float4>();
     a.cq = s->qbuf[1].as<float4>();
     a.qcap = s->n_slots;
@@ -1323,6 +1366,21 @@ __global__ void k_hg_update(const float4* vp2, const float* phi, const int32_t* 
     }
     planes[9 * np + px] = newN;
     planes[11 * np + px] = newR;
+}
+// Film::writeImage (src/core/TkFilm.cpp:124-153): contribSum / filterWeightSum, gamma 0.6, rows bottom-up.
+// Planes: 0..2 contribSum, 9 filterWeightSum.
+__global__ void k_pt_resolve(const float* planes, int64_t np, int W, int H, uint8_t* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const int x = (int)(i % W), y = (int)(i / W);
+    const float wsum = planes[9 * np + i];
+    uint8_t* o = out + ((int64_t)(H - 1 - y) * W + x) * 3;
+    for (int c = 0; c < 3; ++c) {
+        float v = planes[c * np + i];
+        if (wsum != 0) v = v / wsum;
+        const float cl = sse_max(sse_min(v, 1.0f), 0.0f);
+        o[c] = (uint8_t)(255 * powf(cl, 0.6f));
+    }
 }
 // The final image (src/TkSPPM.cpp:436-450), rows bottom-up.
 __global__ void k_hg_resolve(const float* planes, int64_t np, int W, int H, int iterations, int photons_per_it, uint8_t* out) {
@@ -1930,6 +1988,57 @@ int tkhip_hsppm_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out) {
     TK_TRY(ctx->scratch_a.ensure(bytes));
     k_hg_resolve<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, ctx->cam.w, ctx->cam.h,
                                                                   s->num_recurse, s->prm.globalSize, ctx->scratch_a.as<uint8_t>());
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(host_out, ctx->scratch_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+/* ---- path tracer ---- */
+int tkhip_pt_begin(tkhip_ctx* ctx, int spp, int max_depth, float rr, uint64_t seed) {
+    TK_REQUIRE(ctx, TKHIP_E_ARG, "tkhip_pt_begin: null context");
+    TK_REQUIRE(spp >= 1 && (spp & (spp - 1)) == 0, TKHIP_E_ARG, "tkhip_pt_begin: spp must be a power of two (RayTracer rounds it up)");
+    TkSppmParam p{};
+    p.numRecurse = 1; p.globalSize = 1; p.globalSample = 1; p.causticSize = 0; p.causticSample = 1; p.radius2 = 1.f;
+    TK_TRY(tkhip_sppm_begin(ctx, &p, max_depth, rr, seed, 0, 1));
+    SppmState* s = ctx->sppm;
+    s->pt_mode = true;
+    s->pt_next_sample = 0;
+    // strata of the pixel sampler (PathTracer ctor, src/tracer/TkPathTracer.cpp:16-22)
+    int x = 1, y = spp / x;
+    while (y != x && y / x != 2) { x <<= 1; y = spp / x; }
+    s->xs = x; s->ys = y; s->num_recurse = spp;
+    // the film starts empty: contribSum and filterWeightSum zero (Film::clear)
+    TK_HIP(hipMemsetAsync(s->planes.p, 0, (size_t)s->n_pixels * 13 * 4, ctx->stream));
+    TK_HIP(hipStreamSynchronize(ctx->stream));
+    return TKHIP_OK;
+}
+
+int tkhip_pt_render_samples(tkhip_ctx* ctx, int count, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_pt_render_samples");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->pt_mode, TKHIP_E_STATE, "tkhip_pt_render_samples: the render was not begun with tkhip_pt_begin");
+    TK_REQUIRE(count >= 0 && s->pt_next_sample + count <= s->num_recurse, TKHIP_E_ARG,
+               "tkhip_pt_render_samples: %d samples asked, %d of %d left", count, s->num_recurse - s->pt_next_sample, s->num_recurse);
+    const double t0 = now_ms();
+    if (st) memset(st, 0, sizeof(*st));
+    for (int i = 0; i < count; ++i) {
+        TK_TRY(camera_trace(ctx, s->pt_next_sample, false));
+        if (st) TK_TRY(collect_rays(ctx, 2, st));
+        ++s->pt_next_sample;
+    }
+    if (st) st->ms_camera = st->ms_total = (float)(now_ms() - t0);
+    return TKHIP_OK;
+}
+
+int tkhip_pt_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out) {
+    TK_CTX_SPPM(ctx, "tkhip_pt_resolve_rgb8");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->pt_mode && host_out, TKHIP_E_STATE, "tkhip_pt_resolve_rgb8: no path-tracer render, or null buffer");
+    const size_t bytes = (size_t)s->n_pixels * 3;
+    TK_TRY(ctx->scratch_a.ensure(bytes));
+    k_pt_resolve<<<divup(s->n_pixels, 256), 256, 0, ctx->stream>>>(s->planes.as<float>(), s->n_pixels, ctx->cam.w, ctx->cam.h,
+                                                                  ctx->scratch_a.as<uint8_t>());
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(host_out, ctx->scratch_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     TK_HIP(hipStreamSynchronize(ctx->stream));

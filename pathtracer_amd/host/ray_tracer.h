@@ -110,9 +110,22 @@ public:
     void render(std::string filename) override;
 };
 
+// <tracer type="pt">: the reference's path tracer (src/tracer/TkPathTracer.h:9-19) on the path
+// kernels.  One step of the state machine adds one sample per pixel to the film (the reference
+// advances tile by tile); the BVH visualisation of the windowed program is not carried over.
+class PathTracer : public RayTracer {
+    int mDone = 0;                        // samples per pixel in the film so far
+    void rendering() override;
+public:
+    PathTracer(int spp, int maxDepth, int numThreads, float russianRoulette);
+    void startRaytracing() override;
+    void saveImage(std::string filename = "") override;
+    void render(std::string filename) override;
+};
+
 // parse_tracer's dispatch on the type attribute (src/TkLoader.cpp:238-262).
-// "sppm" (tk::SppmTracer) and "sppm_hash" (tk::SPPM, chosen by <hashgrid i="1"/>) have a device path;
-// the other integrators return null with a message in *error.
+// "sppm" (tk::SppmTracer), "sppm_hash" (tk::SPPM, chosen by <hashgrid i="1"/>) and "pt"
+// (tk::PathTracer) have a device path; "bdpt" and "light" return null with a message in *error.
 std::unique_ptr<RayTracer> createTracer(const TkTracerConfig& cfg, std::string* error);
 
 }  // namespace tk

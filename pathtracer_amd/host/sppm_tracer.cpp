@@ -1,4 +1,5 @@
 // sppm_tracer.cpp — host-side tracer classes driving the device backend.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -336,14 +337,77 @@ void SPPM::render(std::string filename) {   // src/TkSPPM.cpp:347-465
     if (mState == DONE) saveImage(filename);
 }
 
+// ------------------------------------------------------------ path tracer
+PathTracer::PathTracer(int spp, int maxDepth, int numThreads, float russianRoulette)
+    : RayTracer(spp, maxDepth, numThreads, russianRoulette) {}
+
+void PathTracer::startRaytracing() {
+    if (mState != READY) return;
+    mDone = 0;
+    releaseDevice();
+    if (mGpus > 1) fprintf(stderr, "\r[Tracer] the path tracer renders on one GPU; --gpus ignored\n");
+    mGpus = 1;
+    if (!uploadScene()) return;
+    if (tkhip_pt_begin(mCtx, mSpp, mMaxDepth, mRussianRoulette, mSeed) != 0) {
+        fail("tkhip_pt_begin");
+        return;
+    }
+    RayTracer::startRaytracing();
+}
+
+void PathTracer::rendering() {   // src/tracer/TkPathTracer.cpp:114-125: progress, done when all work is handed out
+    if (mState != RENDERING) return;
+    if (tkhip_pt_render_samples(mCtx, 1, nullptr) != 0) {
+        fail("tkhip_pt_render_samples");
+        mState = READY;
+        return;
+    }
+    ++mDone;
+    fprintf(stderr, "\r[Tracer] Rendering...... %02d%%", std::min(mDone * 100 / mSpp, 100));
+    if (mDone >= mSpp) {
+        fprintf(stderr, "\n");
+        mState = DONE;
+    }
+}
+
+void PathTracer::saveImage(std::string filename) {   // RayTracer::saveImage -> Film::writeImage
+    if (mState != DONE && mState != RENDERING) return;
+    if (filename.empty()) filename = "binary.ppm";
+    std::vector<uint8_t> rgb(size_t(mWidth) * size_t(mHeight) * 3);
+    if (tkhip_pt_resolve_rgb8(mCtx, rgb.data()) != 0) {
+        fail("tkhip_pt_resolve_rgb8");
+        return;
+    }
+    fprintf(stderr, "\n[Tracer] Saving to file: %s... ", filename.c_str());
+    if (tkhost_write_ppm(filename.c_str(), mWidth, mHeight, rgb.data()) == 0) fprintf(stderr, "Done!\n");
+    else fprintf(stderr, "FAILED\n");
+}
+
+void PathTracer::render(std::string filename) {   // RayTracer::render, src/core/TkRayTracer.cpp:142-190
+    startRaytracing();
+    if (mState == RENDERING) {
+        if (tkhip_pt_render_samples(mCtx, mSpp, nullptr) != 0) {
+            fail("tkhip_pt_render_samples");
+            mState = READY;
+            return;
+        }
+        mDone = mSpp;
+        fprintf(stderr, "\r[Tracer] Rendering...... 100%%\n");
+        mState = DONE;
+    }
+    if (mState == DONE) saveImage(filename);
+}
+
 std::unique_ptr<RayTracer> createTracer(const TkTracerConfig& cfg, std::string* error) {
     std::string type = cfg.type;
+    if (type == "pt")
+        return std::unique_ptr<RayTracer>(new PathTracer(cfg.spp, cfg.max_depth, cfg.num_threads, cfg.russian_roulette));
     if (type == "sppm_hash")
         return std::unique_ptr<RayTracer>(new SPPM(cfg.spp, cfg.max_depth, cfg.num_threads, cfg.russian_roulette, cfg.sppm));
     if (type == "sppm")
         return std::unique_ptr<RayTracer>(
             new SppmTracer(cfg.spp, cfg.max_depth, cfg.num_threads, cfg.russian_roulette, cfg.sppm));
-    if (error) *error = "tracer type '" + type + "' has no device path (only 'sppm' is accelerated)";
+    if (error) *error = "tracer type '" + type + "' has no device path ('sppm' and 'pt' are accelerated)";
     return nullptr;
 }
 

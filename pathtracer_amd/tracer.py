@@ -377,6 +377,43 @@ class SppmTracer:
             self.ctx = None
 
 
+class PathTracer:
+    """tk::PathTracer on the GPU (tkhip_pt_*): spp samples per pixel into the box-filter film."""
+
+    def __init__(self, scene, spp, max_depth, rr, width, height, device=0, seed=0x5EED):
+        self.ctx = Context(device)
+        self.ctx.set_scene(scene)
+        self.ctx.set_camera(scene, width, height)
+        self.width, self.height, self.spp = width, height, spp
+        check(self.ctx.lib, self.ctx.lib.tkhip_pt_begin(self.ctx.h, spp, max_depth, rr, seed), "tkhip_pt_begin")
+
+    def set_jitter(self, on):
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_set_jitter(self.ctx.h, 1 if on else 0), "tkhip_sppm_set_jitter")
+
+    def render_samples(self, count):
+        st = _abi.TkIterStats()
+        check(self.ctx.lib, self.ctx.lib.tkhip_pt_render_samples(self.ctx.h, count, C.byref(st)), "tkhip_pt_render_samples")
+        return st
+
+    def film(self):
+        """(contribSum (H*W, 3), filterWeightSum (H*W,))"""
+        n = self.width * self.height
+        buf = (_abi.TkSPPMPixel * n)()
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_read_pixels(self.ctx.h, buf), "tkhip_sppm_read_pixels")
+        px = np.frombuffer(buf, dtype=np.float32).reshape(n, 13)
+        return px[:, 0:3].copy(), px[:, 9].copy()
+
+    def resolve(self):
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        check(self.ctx.lib, self.ctx.lib.tkhip_pt_resolve_rgb8(self.ctx.h, _bp(out)), "tkhip_pt_resolve_rgb8")
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.ctx.close()
+            self.ctx = None
+
+
 class HashGridSppm:
     """The hash-grid SPPM variant (tkhip_hsppm_*): visible point per pixel, photons deposited through a
     spatial hash grid.  param.globalSize = light paths per iteration, param.radius2 = the initial radius."""
