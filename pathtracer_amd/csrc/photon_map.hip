@@ -501,6 +501,7 @@ TKD unsigned long long wave_select_prune(unsigned long long* keys, uint32_t* pay
 // the candidate buffer.  Lanes [lane0, lane0+32) of the wave serve this leaf.
 static_assert(64 % kLeafCap == 0, "a step of a gather kernel serves 64 / kLeafCap leaves, one photon per lane");
 constexpr int kLeavesPerStep = 64 / kLeafCap;
+constexpr int kSortFrontierFrom = 20;   // the per-query kernel orders its leaves by distance from this many on
 
 // What the grouped kernel hands to the per-query kernel with a query: the group it was in, and per
 // group the leaves under the union of its search boxes (at most kMaxGroupLeaves <= 64).
@@ -619,8 +620,82 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                 fcount = ncount;
             }
             if (fits) {
-                for (int i = 0; i < fcount; i += kLeavesPerStep)
-                    take_leaves(&front[cur][i], fcount - i < kLeavesPerStep ? fcount - i : kLeavesPerStep);
+                // The leaves of the frontier, 64 at a time, nearest first (every lane ranks its leaf's box
+                // distance among the others'), so that the first cut brings the bound close to its final
+                // value and the leaves beyond it are never loaded.  The photons of a step are requested
+                // one step ahead of their tests.
+                int* fr = front[cur];
+                int* sorted = front[cur ^ 1];
+                auto fetch = [&](const int* nodes, int count_nodes, float4* pp, uint32_t* at) {
+                    const int slot = lane / kLeafCap, ph = lane % kLeafCap;
+                    bool has = false;
+                    if (slot < count_nodes) {
+                        const int leaf = nodes[slot] - mv.nl;
+                        const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
+                        if (ph < (int)(e0 - s0)) {
+                            *at = (uint32_t)(s0 + ph);
+                            *pp = mv.pos4[*at];
+                            has = true;
+                        }
+                    }
+                    return has;
+                };
+                auto test = [&](bool has, float4 pp, uint32_t at) {
+                    bool acc = false;
+                    unsigned long long key = 0;
+                    if (has) {
+                        const float d2 = dist2_exact(pp.x, pp.y, pp.z, Q.p);
+                        key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(pp.w);
+                        acc = key < bound;
+                    }
+                    const unsigned long long m = __ballot(acc);
+                    if (m) {
+                        const int dst = count + __popcll(m & lt_mask);
+                        if (acc) { keys[dst] = key; pay[dst] = at; }
+                        count += __popcll(m);
+                        if (count > CAP - 64) {
+                            bound = wave_select_prune<EPL>(keys, pay, &count, k, lane, bound_d2, s_hist[wave], s_cand[wave]);
+                            bound_d2 = __uint_as_float((uint32_t)(bound >> 32) + 1u);
+                        }
+                    }
+                };
+                for (int c0 = 0; c0 < fcount; c0 += 64) {
+                    const int nc = fcount - c0 < 64 ? fcount - c0 : 64;
+                    const int node = lane < nc ? fr[c0 + lane] : 0;
+                    const float d = lane < nc ? box_dist2(mv, node, Q.p) : INFINITY;
+                    int rank = lane;
+                    if (fcount > kSortFrontierFrom) {   // a short list is scanned whole anyway: tree order will do
+                        rank = 0;
+                        for (int j = 0; j < nc; ++j) {
+                            const float dj = lane_f(d, j);
+                            rank += (dj < d || (dj == d && j < lane)) ? 1 : 0;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < nc) { sorted[rank] = node; st_d2[rank] = d; }
+                    __builtin_amdgcn_wave_barrier();
+                    // how many leaves of step i are still within the bound: 0 ends the chunk
+                    const bool by_distance = fcount > kSortFrontierFrom;
+                    auto within = [&](int i) {
+                        if (i >= nc) return 0;
+                        if (!by_distance) return i + 1 < nc ? 2 : 1;
+                        if (!(uniform_f(st_d2[i]) < uniform_f(bound_d2))) return 0;
+                        return (i + 1 < nc && uniform_f(st_d2[i + 1]) < uniform_f(bound_d2)) ? 2 : 1;
+                    };
+                    float4 pp_next = make_float4(0, 0, 0, 0);
+                    uint32_t at_next = 0;
+                    int n_next = within(0);
+                    bool has_next = n_next > 0 && fetch(&sorted[0], n_next, &pp_next, &at_next);
+                    for (int i = 0; n_next > 0; i += kLeavesPerStep) {
+                        const float4 pp = pp_next;
+                        const uint32_t at = at_next;
+                        const bool has = has_next;
+                        n_next = within(i + kLeavesPerStep);
+                        has_next = n_next > 0 && fetch(&sorted[i + kLeavesPerStep], n_next, &pp_next, &at_next);
+                        test(has, pp, at);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
                 done = true;
             }
         }
@@ -995,7 +1070,17 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
 // Hilbert key of every query inside the root box of the tree.  Consecutive
 // queries in this order are neighbours in space (a Hilbert curve has no jumps,
 // unlike a Morton curve), so the search boxes of the 64 queries of a wave overlap.
-__global__ void k_query_curve(QueryView qv, int64_t nq, const float4* root_box, uint32_t* keys, uint32_t* vals) {
+// The order of the queries along the curve does not have to be exact: what the grouped kernel needs is that
+// the 64 queries of a wave are neighbours in space.  So instead of a full sort the queries are dealt into
+// 2^bits buckets by the leading bits of their curve index (a count, a prefix sum, a placement): the buckets
+// are in curve order; inside a bucket (a handful of queries) the atomics' order is replaced by the order of
+// (pixel, query number) - every query counts the smaller ones in its bucket - so the grouping is the same on
+// every run even though the camera pass appends its queries in whatever order its waves finish: which kernel
+// finishes a query, and with it the last bits of its flux sum, depends on its group.
+constexpr int kQueryBucketBitsMax = 21;
+constexpr int kQueryBucketRankCap = 4096;   // larger buckets (every query in one spot) keep the atomics' order
+__global__ void k_query_bucket(QueryView qv, int64_t nq, const float4* root_box, int shift, int32_t* bucket_count,
+                               uint32_t* bucket_of, uint32_t* rank_in) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const float4 b0 = root_box[0], b1 = root_box[1];
@@ -1004,8 +1089,37 @@ __global__ void k_query_curve(QueryView qv, int64_t nq, const float4* root_box, 
     float fx = fminf(fmaxf((a.x - b0.x) * (ex > 0 ? 1023.f / ex : 0.f), 0.f), 1023.f);
     float fy = fminf(fmaxf((a.y - b0.y) * (ey > 0 ? 1023.f / ey : 0.f), 0.f), 1023.f);
     float fz = fminf(fmaxf((a.z - b0.z) * (ez > 0 ? 1023.f / ez : 0.f), 0.f), 1023.f);
-    keys[i] = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz);
-    vals[i] = (uint32_t)i;
+    const uint32_t b = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz) >> shift;
+    bucket_of[i] = b;
+    rank_in[i] = (uint32_t)atomicAdd(&bucket_count[b], 1);
+}
+__global__ void k_query_place(QueryView qv, int64_t nq, const uint32_t* bucket_of, const uint32_t* rank_in,
+                              const int32_t* bucket_start, uint32_t* placed_pixel, uint32_t* placed_index) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const uint32_t at = (uint32_t)bucket_start[bucket_of[i]] + rank_in[i];
+    placed_pixel[at] = __float_as_uint(qv.q2[i].w);
+    placed_index[at] = (uint32_t)i;
+}
+__global__ void k_query_rank(QueryView qv, int64_t nq, const uint32_t* bucket_of, const uint32_t* rank_in,
+                             const int32_t* bucket_start, const uint32_t* placed_pixel, const uint32_t* placed_index,
+                             uint32_t* order) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const uint32_t b = bucket_of[i];
+    const int s0 = bucket_start[b], e0 = bucket_start[b + 1];
+    if (e0 - s0 > kQueryBucketRankCap) {   // the bucket stays as the atomics placed it
+        order[(uint32_t)s0 + rank_in[i]] = (uint32_t)i;
+        return;
+    }
+    const uint32_t mine = __float_as_uint(qv.q2[i].w);
+    int rank = 0;
+    for (int p = s0; p < e0; ++p) {
+        const uint32_t px = placed_pixel[p];
+        if (px < mine) ++rank;
+        else if (px == mine && placed_index[p] < (uint32_t)i) ++rank;   // stand-alone gathers: every query of pixel 0
+    }
+    order[s0 + rank] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------ host side
@@ -1186,7 +1300,9 @@ int map_reserve_queries(tkhip_map* m, int64_t nq) {
     TK_TRY(m->overflow_group.ensure((size_t)nq * 4));
     TK_TRY(m->group_leaves.ensure((size_t)((nq + 63) / 64) * kMaxGroupLeaves * 4));
     TK_TRY(m->group_leaf_count.ensure((size_t)((nq + 63) / 64) * 4));
-    TK_TRY(sort_pairs_u32_reserve(m->prim_temp, (size_t)nq, 30));
+    size_t scan_bytes = 0;
+    TK_TRY(exclusive_scan_i32_temp_bytes(((size_t)1 << kQueryBucketBitsMax) + 1, &scan_bytes));
+    TK_TRY(m->prim_temp.ensure(2 * ((((size_t)1 << kQueryBucketBitsMax) + 1) * 4 + 256) + scan_bytes + 256));
     return TKHIP_OK;
 }
 
@@ -1256,10 +1372,26 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
         TK_LAUNCH_CHECK();
         return TKHIP_OK;
     }
-    // Hilbert order inside the root box of the tree (heap node 1)
-    k_query_curve<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, sc.q_keys_a, sc.q_vals_a);
+    // Curve order inside the root box of the tree (heap node 1), to the bucket: about one bucket per query
+    int bits = 6;
+    while (bits < kQueryBucketBitsMax && ((int64_t)1 << bits) <= 2 * nq) ++bits;   // surfaces fill few cells: two buckets per query
+    const size_t nb = (size_t)1 << bits;
+    const size_t arr = ((nb + 1) * 4 + 255) & ~(size_t)255;
+    TK_REQUIRE(sc.sort_temp_bytes > 2 * arr, TKHIP_E_LIMIT, "gather: %zu bytes of scratch for the query buckets, %zu given", 2 * arr,
+               sc.sort_temp_bytes);
+    int32_t* bucket_count = static_cast<int32_t*>(sc.sort_temp);
+    int32_t* bucket_start = reinterpret_cast<int32_t*>(static_cast<char*>(sc.sort_temp) + arr);
+    TK_HIP(hipMemsetAsync(bucket_count, 0, (nb + 1) * 4, s));
+    k_query_bucket<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, 30 - bits, bucket_count, sc.q_keys_a,
+                                                  sc.q_vals_a);
     TK_LAUNCH_CHECK();
-    TK_TRY(sort_pairs_u32_in(s, sc.sort_temp, sc.sort_temp_bytes, sc.q_keys_a, sc.q_keys_b, sc.q_vals_a, sc.q_order, (size_t)nq, 30));
+    TK_TRY(exclusive_scan_i32_in(s, static_cast<char*>(sc.sort_temp) + 2 * arr, sc.sort_temp_bytes - 2 * arr, bucket_count,
+                                 bucket_start, nb + 1));
+    uint32_t* placed_index = reinterpret_cast<uint32_t*>(sc.q_sorted);   // free until k_sort_queries fills it
+    k_query_place<<<divup(nq, 256), 256, 0, s>>>(qv, nq, sc.q_keys_a, sc.q_vals_a, bucket_start, sc.q_keys_b, placed_index);
+    k_query_rank<<<divup(nq, 256), 256, 0, s>>>(qv, nq, sc.q_keys_a, sc.q_vals_a, bucket_start, sc.q_keys_b, placed_index,
+                                                sc.q_order);
+    TK_LAUNCH_CHECK();
     k_sort_queries<<<divup(nq, 256), 256, 0, s>>>(qv, sc.q_order, nq, sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<float*>(sc.q_keys_a));
     TK_LAUNCH_CHECK();
     int32_t* ocount = sc.counter;          // the hand-over count

@@ -209,6 +209,9 @@ int sort_pairs_u32_temp_bytes(size_t n, int end_bit, size_t* bytes);
 // Grows `temp` to what sort_pairs_u32 of n pairs needs, without sorting.
 int sort_pairs_u32_reserve(DevBuf& temp, size_t n, int end_bit);
 int exclusive_scan_i32(hipStream_t stream, DevBuf& temp, const int32_t* in, int32_t* out, size_t n);
+// The same scan in caller-provided scratch (no allocation; TKHIP_E_LIMIT if too small), and the size it needs.
+int exclusive_scan_i32_in(hipStream_t stream, void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n);
+int exclusive_scan_i32_temp_bytes(size_t n, size_t* bytes);
 
 int upload_direction_tables(tkhip_ctx* ctx);
 // Looks up the address of the library's static gather scratch on `device` (which must be current).
