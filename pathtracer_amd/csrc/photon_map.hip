@@ -348,6 +348,17 @@ TKD float box_dist2(const MapView& mv, int node, F3 p) {
     return (dx * dx + dy * dy + dz * dz) * 0.999999f;
 }
 
+// A query whose search sphere does not reach the root box of the tree finds nothing.  Clamped into the box such
+// queries would pile up in the cells of its faces (a caustic map covers a corner of the scene, the queries all of
+// it: millions in one bucket); they get buckets of their own behind the 2^bits of the curve, dealt by query number:
+// their result does not depend on who their neighbours are.
+TKD bool sphere_misses_box(float4 b0, float4 b1, float px, float py, float pz, float r2) {
+    const float dx = fmaxf(fmaxf(b0.x - px, px - b0.w), 0.f);
+    const float dy = fmaxf(fmaxf(b0.y - py, py - b1.x), 0.f);
+    const float dz = fmaxf(fmaxf(b0.z - pz, pz - b1.y), 0.f);
+    return !((dx * dx + dy * dy + dz * dz) * 0.999999f < r2);
+}
+
 // ------------------------------------------- per-query kernel (one wave each)
 // The wave keeps the candidates of its query in an LDS buffer of 64*EPL
 // (dist2, index) keys and, whenever the buffer could overflow, cuts it back to
@@ -809,6 +820,7 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
     const int k = mv.k;
     const int64_t ngroups = (nq + 63) >> 6;
     int (*front)[FCAP] = s_front[wave];
+    const float4 root0 = mv.node_box[2], root1 = mv.node_box[3];   // box of the whole map (heap node 1)
     unsigned long long found_sum = 0, staged_sum = 0;
     // Groups are handed out one at a time: the waves of the grid (sized to what the GPU holds at once)
     // stay busy until the last group is taken.  Two group indices are kept ahead of the one being worked
@@ -859,7 +871,9 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         Q.n = mk3(cur_q.b.x, cur_q.b.y, cur_q.b.z); Q.won = cur_q.b.w;
         const float r2_in = Q.r2;
         const int pixel = cur_q.pixel;
-        if (!valid || !(Q.r2 > 0.f)) Q.r2 = -1.f;
+        // a query that is not one, or whose search sphere does not reach the photons at all, finds nothing:
+        // it takes no part in the search (its box would stretch the union over empty space)
+        if (!valid || !(Q.r2 > 0.f) || sphere_misses_box(root0, root1, Q.p.x, Q.p.y, Q.p.z, Q.r2)) Q.r2 = -1.f;
         const float rr = Q.r2 > 0.f ? sqrtf(Q.r2) * 1.00001f : -INFINITY;
         // union of the search boxes of the wave
         const float lox = wave_min_all(Q.r2 > 0.f ? Q.p.x - rr : INFINITY);
@@ -1077,19 +1091,35 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
 // (pixel, query number) - every query counts the smaller ones in its bucket - so the grouping is the same on
 // every run even though the camera pass appends its queries in whatever order its waves finish: which kernel
 // finishes a query, and with it the last bits of its flux sum, depends on its group.
-constexpr int kQueryBucketBitsMax = 21;
+constexpr int kQueryBucketBitsMax = 25;
 constexpr int kQueryBucketRankCap = 4096;   // larger buckets (every query in one spot) keep the atomics' order
-__global__ void k_query_bucket(QueryView qv, int64_t nq, const float4* root_box, int shift, int32_t* bucket_count,
+// Buckets of a gather of nq queries: about two per query (surfaces fill few of the cells), 2^bits of them.
+static int query_bucket_bits(int64_t nq) {
+    int bits = 6;
+    while (bits < kQueryBucketBitsMax && ((int64_t)1 << bits) <= 2 * nq) ++bits;
+    return bits;
+}
+// ... and a quarter as many behind them for the queries that cannot reach the map (k_query_bucket)
+static size_t query_bucket_count(int64_t nq) {
+    const int bits = query_bucket_bits(nq);
+    return ((size_t)1 << bits) + ((size_t)1 << (bits - 2));
+}
+__global__ void k_query_bucket(QueryView qv, int64_t nq, const float4* root_box, int bits, int32_t* bucket_count,
                                uint32_t* bucket_of, uint32_t* rank_in) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const float4 b0 = root_box[0], b1 = root_box[1];
     const float ex = b0.w - b0.x, ey = b1.x - b0.y, ez = b1.y - b0.z;
     float4 a = qv.q0[i];
-    float fx = fminf(fmaxf((a.x - b0.x) * (ex > 0 ? 1023.f / ex : 0.f), 0.f), 1023.f);
-    float fy = fminf(fmaxf((a.y - b0.y) * (ey > 0 ? 1023.f / ey : 0.f), 0.f), 1023.f);
-    float fz = fminf(fmaxf((a.z - b0.z) * (ez > 0 ? 1023.f / ez : 0.f), 0.f), 1023.f);
-    const uint32_t b = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz) >> shift;
+    uint32_t b;
+    if (sphere_misses_box(b0, b1, a.x, a.y, a.z, a.w)) {
+        b = (1u << bits) + ((uint32_t)i & ((1u << (bits - 2)) - 1u));
+    } else {
+        float fx = fminf(fmaxf((a.x - b0.x) * (ex > 0 ? 1023.f / ex : 0.f), 0.f), 1023.f);
+        float fy = fminf(fmaxf((a.y - b0.y) * (ey > 0 ? 1023.f / ey : 0.f), 0.f), 1023.f);
+        float fz = fminf(fmaxf((a.z - b0.z) * (ez > 0 ? 1023.f / ez : 0.f), 0.f), 1023.f);
+        b = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz) >> (30 - bits);
+    }
     bucket_of[i] = b;
     rank_in[i] = (uint32_t)atomicAdd(&bucket_count[b], 1);
 }
@@ -1300,9 +1330,10 @@ int map_reserve_queries(tkhip_map* m, int64_t nq) {
     TK_TRY(m->overflow_group.ensure((size_t)nq * 4));
     TK_TRY(m->group_leaves.ensure((size_t)((nq + 63) / 64) * kMaxGroupLeaves * 4));
     TK_TRY(m->group_leaf_count.ensure((size_t)((nq + 63) / 64) * 4));
+    const size_t nb = query_bucket_count(nq);
     size_t scan_bytes = 0;
-    TK_TRY(exclusive_scan_i32_temp_bytes(((size_t)1 << kQueryBucketBitsMax) + 1, &scan_bytes));
-    TK_TRY(m->prim_temp.ensure(2 * ((((size_t)1 << kQueryBucketBitsMax) + 1) * 4 + 256) + scan_bytes + 256));
+    TK_TRY(exclusive_scan_i32_temp_bytes(nb + 1, &scan_bytes));
+    TK_TRY(m->prim_temp.ensure(2 * ((nb + 1) * 4 + 256) + scan_bytes + 256));
     return TKHIP_OK;
 }
 
@@ -1372,17 +1403,16 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
         TK_LAUNCH_CHECK();
         return TKHIP_OK;
     }
-    // Curve order inside the root box of the tree (heap node 1), to the bucket: about one bucket per query
-    int bits = 6;
-    while (bits < kQueryBucketBitsMax && ((int64_t)1 << bits) <= 2 * nq) ++bits;   // surfaces fill few cells: two buckets per query
-    const size_t nb = (size_t)1 << bits;
+    // Curve order inside the root box of the tree (heap node 1), to the bucket
+    const int bits = query_bucket_bits(nq);
+    const size_t nb = query_bucket_count(nq);
     const size_t arr = ((nb + 1) * 4 + 255) & ~(size_t)255;
     TK_REQUIRE(sc.sort_temp_bytes > 2 * arr, TKHIP_E_LIMIT, "gather: %zu bytes of scratch for the query buckets, %zu given", 2 * arr,
                sc.sort_temp_bytes);
     int32_t* bucket_count = static_cast<int32_t*>(sc.sort_temp);
     int32_t* bucket_start = reinterpret_cast<int32_t*>(static_cast<char*>(sc.sort_temp) + arr);
     TK_HIP(hipMemsetAsync(bucket_count, 0, (nb + 1) * 4, s));
-    k_query_bucket<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, 30 - bits, bucket_count, sc.q_keys_a,
+    k_query_bucket<<<divup(nq, 256), 256, 0, s>>>(qv, nq, m->node_box.as<float4>() + 2, bits, bucket_count, sc.q_keys_a,
                                                   sc.q_vals_a);
     TK_LAUNCH_CHECK();
     TK_TRY(exclusive_scan_i32_in(s, static_cast<char*>(sc.sort_temp) + 2 * arr, sc.sort_temp_bytes - 2 * arr, bucket_count,
