@@ -35,7 +35,11 @@ struct GatherScratch {
     uint32_t *q_keys_a, *q_keys_b, *q_vals_a, *q_order;
     float4* q_sorted;            // 2 x nq: q0 and q1 of the queries in the order of the curve
     int32_t *overflow, *overflow_group, *group_leaves, *group_leaf_count;
-    int32_t* counter;            // the hand-over count, cleared per gather
+    int32_t *sel_groups, *sel_cnt;   // groups left to the selection kernel; per query slot: photons met
+    float* q_r2s;                    // per query slot: the radius^2 to search with (the query's own or a smaller bound)
+    int32_t* history;                // 2 ints that outlive the gather: queries of this launch that met k photons, all queries (or null)
+    const int32_t* history_last;     // the same of the map's last launch (or null)
+    int32_t* counter;            // 32 ints, cleared per gather: [0] the hand-over count, [16] the selection kernel's groups
     void* sort_temp;
     size_t sort_temp_bytes;
 };
@@ -45,6 +49,7 @@ struct MapView {
     const float4* pow4;      // leaf order: r, g, b, theta | phi << 8 (int bits)
     const float4* node_box;  // heap order, 2 float4 per node: (mnx,mny,mnz,mxx) (mxy,mxz,-,-)
     const float* dirtab;     // cosTheta[256], sinTheta[256], cosPhi[256], sinPhi[256]
+    const uint32_t* keys;    // leaf order: the photons' cells along the Hilbert curve (ascending), or null (median-split tree)
     int32_t n, nl, depth, k;
 };
 
@@ -60,10 +65,12 @@ struct tkhip_map {
     int nl = 0, depth = 0;
     tkd::DevBuf in_pos, in_pow, in_dir;            // storage order: float3, float3, u16
     tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
+    int history_turn = 0;           // which of the two history pairs in `counters` the next gather counts into
     int tree_mode = 0;              // 0: one sort along a Hilbert curve; 1: median splits, one sort per level
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, q_sorted, overflow, counters;
     tkd::DevBuf overflow_group, group_leaves, group_leaf_count;   // what the grouped kernel hands on with a query
+    tkd::DevBuf sel_groups, sel_cnt, q_r2s;                      // ... and leaves for the selection kernel
     float last_group_ms = 0.f;   // duration of the last grouped gather kernel (timed gathers only)
     int64_t last_overflow = 0;   // queries the last timed gather handed to the per-query kernel
     // Every grouped-kernel launch is bracketed by this pair of events on the map's stream (recording

@@ -359,6 +359,21 @@ TKD bool sphere_misses_box(float4 b0, float4 b1, float px, float py, float pz, f
     return !((dx * dx + dy * dy + dz * dz) * 0.999999f < r2);
 }
 
+// Squared distance from a point to the nearest and to the farthest point of a node box, rounded like a
+// photon's dist2 (no photon of the box is farther than the latter).
+TKD float box_near2(float4 b0, float4 b1, F3 p) {
+    const float dx = fmaxf(fmaxf(b0.x - p.x, p.x - b0.w), 0.f);
+    const float dy = fmaxf(fmaxf(b0.y - p.y, p.y - b1.x), 0.f);
+    const float dz = fmaxf(fmaxf(b0.z - p.z, p.z - b1.y), 0.f);
+    return dx * dx + dy * dy + dz * dz;
+}
+TKD float box_far2(float4 b0, float4 b1, F3 p) {
+    const float dx = fmaxf(fabsf(b0.x - p.x), fabsf(b0.w - p.x));
+    const float dy = fmaxf(fabsf(b0.y - p.y), fabsf(b1.x - p.y));
+    const float dz = fmaxf(fabsf(b0.z - p.z), fabsf(b1.y - p.z));
+    return dx * dx + dy * dy + dz * dz;
+}
+
 // ------------------------------------------- per-query kernel (one wave each)
 // The wave keeps the candidates of its query in an LDS buffer of 64*EPL
 // (dist2, index) keys and, whenever the buffer could overflow, cuts it back to
@@ -517,10 +532,20 @@ constexpr int kSortFrontierFrom = 20;   // the per-query kernel orders its leave
 // What the grouped kernel hands to the per-query kernel with a query: the group it was in, and per
 // group the leaves under the union of its search boxes (at most kMaxGroupLeaves <= 64).
 constexpr int kMaxGroupLeaves = 24 * kLeavesPerStep;
+constexpr int kGroupLeafStride = 64 * kLeavesPerStep;   // longer lists (up to this) are for the selection kernel only
 struct GroupLeaves {
     int32_t* query_group;   // per entry of the hand-over list: group, or -1 (search from the root)
-    int32_t* leaves;        // kMaxGroupLeaves node numbers per group
+    int32_t* leaves;        // kGroupLeafStride node numbers per group
     int32_t* count;
+};
+// What the grouped kernel leaves for the selection kernel: the groups in which many lanes met k photons or more.
+struct SelectWork {
+    int32_t* groups;      // group numbers
+    int32_t* count;       // how many
+    int32_t* slot_cnt;    // per query slot (curve order) of such a group: photons inside the search radius, -1: nothing to select
+    int32_t* history;     // [0] queries of this launch that met k photons or more, [1] all of them (or null)
+    const int32_t* history_last;   // the same of the map's last launch (or null: as if all had)
+    int min_groups;       // fewer groups than this cannot fill the GPU: their lanes go to the per-query kernel
 };
 
 template <int EPL>
@@ -601,7 +626,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
             const int gid = (list && gl.query_group) ? gl.query_group[w] : -1;
             if (gid >= 0) {
                 const int have = gl.count[gid];
-                const int node = lane < have ? gl.leaves[(int64_t)gid * kMaxGroupLeaves + lane] : 0;
+                const int node = lane < have ? gl.leaves[(int64_t)gid * kGroupLeafStride + lane] : 0;
                 const bool keep = lane < have && box_dist2(mv, node, Q.p) < bound_d2;
                 const unsigned long long m = __ballot(keep);
                 if (keep) front[cur][__popcll(m & lt_mask)] = node;
@@ -787,24 +812,119 @@ struct SortedQueries {
     const float4* q0;     // p.xyz, radius^2
     const float4* q1;     // n.xyz, dot(wo, n)
     const float* pixel;   // pixel index (int bits)
+    const float* r2s;     // radius^2 to search with: the query's own, or one cut by k_query_bound
 };
-__global__ void k_sort_queries(QueryView qv, const uint32_t* order, int64_t nq, float4* q0s, float4* q1s, float* pixel) {
+__global__ void k_sort_queries(QueryView qv, const uint32_t* order, int64_t nq, float4* q0s, float4* q1s, float* pixel,
+                               float* r2s) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const int64_t q = order[i];
-    q0s[i] = qv.q0[q];
+    const float4 a = qv.q0[q];
+    q0s[i] = a;
     q1s[i] = qv.q1[q];
     pixel[i] = qv.q2[q].w;
+    r2s[i] = a.w;
+}
+
+// Radii far larger than the photon spacing (the first iterations of a render, dense maps) make every gather
+// wade through thousands of photons for its k nearest.  This kernel cuts such a radius beforehand: a lane
+// looks up a node of at least k photons near its query (by the query's place on the curve the photons are
+// sorted along, or, in a median-split tree, by walking down to the nearer child at every level); the
+// k-th smallest dist2 among the photons of that node bounds the dist2 of the k-th nearest photon of the
+// whole map from above, and the k nearest inside a sphere that holds k photons or more are the k nearest
+// inside any larger one.  The k-th smallest is taken to the upper edge of its bin among kSelBins bins of
+// dist2 up to the radius (or the node's far corner when that is nearer).  The kernel ends at once when few
+// gathers of the map's last launch met k photons (history[0] of history[1]): then radii are small already.
+constexpr int kSelBins = 32;        // histogram bins of a lane (two 16-bit counters to a word: kSelBins / 2 words)
+__global__ void __launch_bounds__(256) k_query_bound(MapView mv, int64_t nq, const float4* q0s, float* r2s,
+                                                     const int32_t* history, int level) {
+    __shared__ uint32_t s_hist[kSelBins / 2][256];
+    if (history && (int64_t)history[0] * 4 < (int64_t)history[1]) return;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float4 a = q0s[i];
+    const F3 p = mk3(a.x, a.y, a.z);
+    const float r2 = a.w;
+    if (!(r2 > 0.f) || sphere_misses_box(mv.node_box[2], mv.node_box[3], p.x, p.y, p.z, r2)) return;
+    int node = 1;
+    if (mv.keys) {
+        // the photons lie in the order of their cells along the curve: the node around the place of the query's cell
+        const float4 b0 = mv.node_box[2], b1 = mv.node_box[3];
+        const float ex = b0.w - b0.x, ey = b1.x - b0.y, ez = b1.y - b0.z;
+        const float fx = fminf(fmaxf((p.x - b0.x) * (ex > 0 ? 1023.f / ex : 0.f), 0.f), 1023.f);
+        const float fy = fminf(fmaxf((p.y - b0.y) * (ey > 0 ? 1023.f / ey : 0.f), 0.f), 1023.f);
+        const float fz = fminf(fmaxf((p.z - b0.z) * (ez > 0 ? 1023.f / ez : 0.f), 0.f), 1023.f);
+        const uint32_t key = hilbert30((uint32_t)fx, (uint32_t)fy, (uint32_t)fz);
+        int64_t lo = 0, hi = mv.n;          // first photon whose key is not below the query's
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (mv.keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        const int64_t at = lo < mv.n ? lo : (int64_t)mv.n - 1;
+        const int64_t leaf = ((at + 1) * mv.nl - 1) / mv.n;     // the leaf photon `at` lies in: inverse of leaf_start
+        node = (1 << level) + (int)(leaf >> (mv.depth - level));
+    } else {
+        for (int l = 0; l < level; ++l) {   // the nearer child at every level
+            const float4 a0 = mv.node_box[4 * (int64_t)node], a1 = mv.node_box[4 * (int64_t)node + 1];
+            const float4 c0 = mv.node_box[4 * (int64_t)node + 2], c1 = mv.node_box[4 * (int64_t)node + 3];
+            const float n0 = box_near2(a0, a1, p), n1 = box_near2(c0, c1, p);
+            const bool right = n1 < n0 || (n1 == n0 && box_far2(c0, c1, p) < box_far2(a0, a1, p));
+            node = 2 * node + (right ? 1 : 0);
+        }
+    }
+    // no photon of the node is farther than its far corner (dist2 and this are rounded alike, term by term)
+    const float far2 = box_far2(mv.node_box[2 * (int64_t)node], mv.node_box[2 * (int64_t)node + 1], p) * 1.00001f;
+    const float top = fminf(far2, r2);
+    const int h = mv.depth - level;
+    const int64_t j = node - (1 << level);
+    const int64_t s0 = leaf_start(j << h, mv.n, mv.depth), e0 = leaf_start((j + 1) << h, mv.n, mv.depth);
+    const float scale = ((float)kSelBins - 0.5f) / top;
+#pragma unroll
+    for (int r = 0; r < kSelBins / 2; ++r) s_hist[r][threadIdx.x] = 0u;
+    for (int64_t at = s0; at < e0; ++at) {
+        const float4 pp = mv.pos4[at];
+        const int b = (int)fminf(dist2_exact(pp.x, pp.y, pp.z, p) * scale, (float)(kSelBins - 1));   // the last bin: beyond, too
+        atomicAdd(&s_hist[b >> 1][threadIdx.x], 1u << ((b & 1) * 16));   // the lane's own column
+    }
+    int cum = 0, bstar = kSelBins - 1;
+    bool hit = false;
+#pragma unroll
+    for (int r = 0; r < kSelBins / 2; ++r) {
+        const uint32_t v = s_hist[r][threadIdx.x];
+        const int c0 = (int)(v & 0xffffu), c1 = (int)(v >> 16);
+        if (!hit) { cum += c0; if (cum >= mv.k) { hit = true; bstar = 2 * r; } }
+        if (!hit) { cum += c1; if (cum >= mv.k) { hit = true; bstar = 2 * r + 1; } }
+    }
+    // every photon counted up to bin bstar < kSelBins - 1 has int(dist2 * scale) <= bstar: dist2 below this edge
+    const float edge = (hit && bstar < kSelBins - 1) ? (float)(bstar + 1) / scale * 1.00001f : far2;
+    const float cut = fminf(far2, edge);
+    if (cut > 0.f && cut < r2) r2s[i] = cut;
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+// Selection of the k nearest inside the grouped kernel (groups in which many queries meet k photons
+// or more: the first iterations of a render, large maps).  Every such lane narrows a window of
+// dist2 that holds its k-th nearest photon: the photons of the group's leaves are streamed again
+// and counted into kSelBins equal bins of dist2 per lane; the bin of the k-th is refined the same
+// way while it holds more than kSelStash photons, then collected: everything below the bin is in,
+// the few photons of the bin are ranked by (dist2, photon index).  bin = int(dist2 * scale) - off
+// with scale a power-of-two multiple of the first window's, so that the bins of a refinement nest
+// exactly in the bin they refine and every pass classifies a photon the same way.
+constexpr int kSelStash = 8;        // photons of the final bin a lane can rank (<= kSelBins / 2: same words)
+constexpr int kSelMinLanes = 48;    // a group with fewer lanes at k or above hands them to the per-query kernel
+constexpr int kSelMinLanesLarge = 32;      // ... in a map of more than kSelLargeMap photons (it does not fit the caches, and
+constexpr int64_t kSelLargeMap = 1 << 20;  //     the per-query kernel pays for that query by query)
+constexpr int kSelMinGroups = 2048; // ... and so do all groups when they are fewer than this (half the waves a GPU holds)
+constexpr int kSelMaxPasses = 5;
+static_assert(kSelStash <= kSelBins / 2, "the stash of a lane reuses the words of its histogram");
+
 template <bool WANT_IDX>
-__global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, SortedQueries qs, const uint32_t* order,
+__global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView qv, SortedQueries qs, const uint32_t* order,
                                                       int64_t nq, GatherOut out, int32_t* overflow, int32_t* overflow_count,
-                                                      GroupLeaves gl) {
-    constexpr int FCAP = 64 * kLeavesPerStep;
+                                                      GroupLeaves gl, SelectWork sw, int sel_min_lanes) {
+    constexpr int FCAP = kGroupLeafStride;
     __shared__ float s_tab[1024];
     // candidates of the current step, struct of arrays so that four of them load as one float4
     __shared__ __align__(16) float s_x[4][64];
@@ -822,20 +942,24 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
     int (*front)[FCAP] = s_front[wave];
     const float4 root0 = mv.node_box[2], root1 = mv.node_box[3];   // box of the whole map (heap node 1)
     unsigned long long found_sum = 0, staged_sum = 0;
+    int flagged_sum = 0;     // queries of this wave that met k photons or more (what the next launch goes by)
+    // many gathers of the map's last launch met k photons or more
+    const bool heavy = sw.history_last == nullptr || (int64_t)sw.history_last[0] * 4 >= (int64_t)sw.history_last[1];
     // Groups are handed out one at a time: the waves of the grid (sized to what the GPU holds at once)
     // stay busy until the last group is taken.  Two group indices are kept ahead of the one being worked
     // on, and the queries of the next group are loaded while the current one is worked on, so that a
     // group does not start with a chain of memory round trips.
-    struct Pre { float4 a, b; int q, pixel; bool valid; };
+    struct Pre { float4 a, b; int q, pixel; float r2s; bool valid; };
     auto prefetch = [&](int64_t g) {
         Pre P;
         const int64_t slot = g * 64 + lane;
         P.valid = g < ngroups && slot < nq;
-        P.a = make_float4(0, 0, 0, -1.f); P.b = make_float4(0, 0, 0, 0); P.q = 0; P.pixel = 0;
+        P.a = make_float4(0, 0, 0, -1.f); P.b = make_float4(0, 0, 0, 0); P.q = 0; P.pixel = 0; P.r2s = -1.f;
         if (P.valid) {
             P.a = qs.q0[slot]; P.b = qs.q1[slot];          // in the order of the curve: coalesced
             P.q = (int)order[slot];
             P.pixel = __float_as_int(qs.pixel[slot]);
+            P.r2s = qs.r2s[slot];
         }
         return P;
     };
@@ -871,6 +995,9 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
         Q.n = mk3(cur_q.b.x, cur_q.b.y, cur_q.b.z); Q.won = cur_q.b.w;
         const float r2_in = Q.r2;
         const int pixel = cur_q.pixel;
+        // a radius cut by k_query_bound holds k photons or more: such a lane ends up selected or handed on
+        const bool shrunk = cur_q.r2s < r2_in;
+        Q.r2 = cur_q.r2s;
         // a query that is not one, or whose search sphere does not reach the photons at all, finds nothing:
         // it takes no part in the search (its box would stretch the union over empty space)
         if (!valid || !(Q.r2 > 0.f) || sphere_misses_box(root0, root1, Q.p.x, Q.p.y, Q.p.z, Q.r2)) Q.r2 = -1.f;
@@ -931,9 +1058,12 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
                 level += jump;
             }
             // A wave that would have to stream far more leaves than its neighbours (its queries straddle
-            // two surfaces, or one of them still has a large radius) would hold up the whole launch.
-            if (fcount > kMaxGroupLeaves) spread = true;
-            TK_STAMP(2)
+            // two surfaces, or one of them still has a large radius) would hold up the whole launch.  While
+            // many gathers meet k photons (first iterations, dense maps) long lists are the rule and are taken.
+            if (fcount > (heavy ? FCAP : kMaxGroupLeaves)) spread = true;
+        }
+        TK_STAMP(2)
+        if (mv.n > 0 && lox <= hix && !spread && fcount > 0) {
             // 2. the photons of those leaves, a step of kLeavesPerStep leaves at a time (one photon per
             //    lane, lane = leaf_slot * kLeafCap + photon), the next step's loads in flight.  A step has
             //    two phases.  A: every lane runs all staged positions against its own query with the exact
@@ -942,97 +1072,110 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
             //    dist2 - radius2 is shifted into the mask.  B: every lane walks the set bits of its mask
             //    and adds those photons' contributions: a tenth of the candidates, so the per-photon
             //    shading work is done for the accepted ones only.
-            if (!spread && fcount > 0) {
-                auto fetch = [&](int i, float4* pp, float4* pw) {
-                    bool has = false;
-                    if (i + leaf_slot < fcount) {
-                        const int leaf = front[cur][i + leaf_slot] - mv.nl;
-                        const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
-                        has = ph < (int)(e0 - s0);
-                        if (has) { *pp = mv.pos4[s0 + ph]; *pw = mv.pow4[s0 + ph]; }
-                    }
-                    return has;
-                };
-                float4 pp = make_float4(0, 0, 0, 0), pw = pp;
-                bool has = fetch(0, &pp, &pw);
-                // negated query position and radius as pairs: dist2 - radius2 is sums and products of pairs
-                const f2v nqx = {-Q.p.x, -Q.p.x}, nqy = {-Q.p.y, -Q.p.y}, nqz = {-Q.p.z, -Q.p.z}, nr2 = {-Q.r2, -Q.r2};
-                // The normal turned to the side wo is on: f() is non-zero when wi and wo are on one side
-                // of the surface, which then reads wi . nw > 0, and |wi . n| = wi . nw there.
-                const float sgn = Q.won > 0.f ? 1.f : (Q.won < 0.f ? -1.f : 0.f);
-                const float nwx = Q.n.x * sgn, nwy = Q.n.y * sgn, nwz = Q.n.z * sgn;
-                const float* const lx = s_x[wave];
-                const float* const ly = s_y[wave];
-                const float* const lz = s_z[wave];
-                for (int i = 0; i < fcount; i += kLeavesPerStep) {
-                    const unsigned long long staged = __ballot(has);
-                    const int n_in = __popcll(staged);
-                    const int n4 = (n_in + 3) & ~3;
-                    __builtin_amdgcn_wave_barrier();      // the previous step has been read by every lane
-                    if (has) {
-                        const int at = __popcll(staged & lt_mask);
-                        F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
-                        s_x[wave][at] = pp.x; s_y[wave][at] = pp.y; s_z[wave][at] = pp.z;
-                        s_rec[wave][at][0] = make_float4(wi.x, wi.y, wi.z, pw.x);
-                        s_rec[wave][at][1] = make_float4(pw.y, pw.z, pp.w, 0.f);
-                    } else {
-                        // the slots up to the next multiple of four hold a position no query accepts
-                        const int at = n_in + __popcll(~staged & lt_mask);
-                        if (at < n4) { s_x[wave][at] = INFINITY; s_y[wave][at] = 0.f; s_z[wave][at] = 0.f; }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    has = i + kLeavesPerStep < fcount ? fetch(i + kLeavesPerStep, &pp, &pw) : false;
-                    staged_sum += (unsigned long long)n_in;
-                    // A: candidate c ends up at bit n4 - 1 - c of the 64-bit mask (m1 : m0)
-                    uint32_t m0 = 0, m1 = 0;
-                    for (int c = 0; c < n4; c += 4) {
-                        const f4v X = *reinterpret_cast<const f4v*>(lx + c);
-                        const f4v Y = *reinterpret_cast<const f4v*>(ly + c);
-                        const f4v Z = *reinterpret_cast<const f4v*>(lz + c);
-                        const f2v dx0 = X.xy + nqx, dy0 = Y.xy + nqy, dz0 = Z.xy + nqz;
-                        const f2v dx1 = X.zw + nqx, dy1 = Y.zw + nqy, dz1 = Z.zw + nqz;
-                        const f2v t0 = (dx0 * dx0 + dy0 * dy0 + dz0 * dz0) + nr2;   // negative: inside (the exact rule, strict)
-                        const f2v t1 = (dx1 * dx1 + dy1 * dy1 + dz1 * dz1) + nr2;
-                        m1 = __builtin_amdgcn_alignbit(m1, m0, 28);
-                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t0.x), 31);
-                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t0.y), 31);
-                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t1.x), 31);
-                        m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t1.y), 31);
-                    }
-                    int wr = cnt;
-                    cnt += __popc(m0) + __popc(m1);
-                    if (!WANT_IDX && cnt >= k) { m0 = 0; m1 = 0; }   // handed on: its sum is not needed
-                    // B: the set bits of m1 (the first n4 - 32 candidates of a step of more than 32), then of
-                    // m0, highest first, i.e. in staging order.  A lane without bits left reads slot 0 and
-                    // adds nothing.
-                    const float4* const rec = &s_rec[wave][0][0];
-                    auto drain = [&](uint32_t w, int n_half, int first) {
-                        while (__any(w != 0)) {
-                            const bool live = w != 0;
-                            const int lzc = __clz(w);
-                            w &= ~(0x80000000u >> (lzc & 31));
-                            const int at = live ? first + lzc + n_half - 32 : 0;   // bit b is candidate n_half - 1 - b of this half
-                            const float4 D = rec[2 * at];
-                            const float2 Wp = *reinterpret_cast<const float2*>(&rec[2 * at + 1]);
-                            const float cs = fmaf(D.x, nwx, fmaf(D.y, nwy, D.z * nwz));
-                            const float wgt = live ? fmaxf(cs, 0.f) : 0.f;
-                            sx = fmaf(D.w, wgt, sx); sy = fmaf(Wp.x, wgt, sy); sz = fmaf(Wp.y, wgt, sz);
-                            if (WANT_IDX) {
-                                if (live && wr < k) out.idx[q * k + wr] = __float_as_int(rec[2 * at + 1].z);
-                                wr += live ? 1 : 0;
-                            }
-                        }
-                    };
-                    if (n4 > 32) { drain(m1, n4 - 32, 0); drain(m0, 32, n4 - 32); }
-                    else drain(m0, n4, 0);
+            auto fetch = [&](int i, float4* pp, float4* pw) {
+                bool has = false;
+                if (i + leaf_slot < fcount) {
+                    const int leaf = front[cur][i + leaf_slot] - mv.nl;
+                    const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
+                    has = ph < (int)(e0 - s0);
+                    if (has) { *pp = mv.pos4[s0 + ph]; *pw = mv.pow4[s0 + ph]; }
                 }
+                return has;
+            };
+            // the photons a step has loaded go to LDS, packed to the front; returns how many
+            auto stage = [&](bool has, float4 pp, float4 pw) {
+                const unsigned long long staged = __ballot(has);
+                const int n_in = __popcll(staged);
+                const int n4 = (n_in + 3) & ~3;
+                __builtin_amdgcn_wave_barrier();      // the previous step has been read by every lane
+                if (has) {
+                    const int at = __popcll(staged & lt_mask);
+                    F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
+                    s_x[wave][at] = pp.x; s_y[wave][at] = pp.y; s_z[wave][at] = pp.z;
+                    s_rec[wave][at][0] = make_float4(wi.x, wi.y, wi.z, pw.x);
+                    s_rec[wave][at][1] = make_float4(pw.y, pw.z, pp.w, 0.f);
+                } else {
+                    // the slots up to the next multiple of four hold a position no query accepts
+                    const int at = n_in + __popcll(~staged & lt_mask);
+                    if (at < n4) { s_x[wave][at] = INFINITY; s_y[wave][at] = 0.f; s_z[wave][at] = 0.f; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                return n_in;
+            };
+            float4 pp = make_float4(0, 0, 0, 0), pw = pp;
+            bool has = fetch(0, &pp, &pw);
+            // negated query position and radius as pairs: dist2 - radius2 is sums and products of pairs
+            const f2v nqx = {-Q.p.x, -Q.p.x}, nqy = {-Q.p.y, -Q.p.y}, nqz = {-Q.p.z, -Q.p.z}, nr2 = {-Q.r2, -Q.r2};
+            // The normal turned to the side wo is on: f() is non-zero when wi and wo are on one side
+            // of the surface, which then reads wi . nw > 0, and |wi . n| = wi . nw there.
+            const float sgn = Q.won > 0.f ? 1.f : (Q.won < 0.f ? -1.f : 0.f);
+            const float nwx = Q.n.x * sgn, nwy = Q.n.y * sgn, nwz = Q.n.z * sgn;
+            const float* const lx = s_x[wave];
+            const float* const ly = s_y[wave];
+            const float* const lz = s_z[wave];
+            const float4* const rec = &s_rec[wave][0][0];
+            for (int i = 0; i < fcount; i += kLeavesPerStep) {
+                const int n_in = stage(has, pp, pw);
+                const int n4 = (n_in + 3) & ~3;
+                has = i + kLeavesPerStep < fcount ? fetch(i + kLeavesPerStep, &pp, &pw) : false;
+                staged_sum += (unsigned long long)n_in;
+                // A: candidate c ends up at bit n4 - 1 - c of the 64-bit mask (m1 : m0)
+                uint32_t m0 = 0, m1 = 0;
+                for (int c = 0; c < n4; c += 4) {
+                    const f4v X = *reinterpret_cast<const f4v*>(lx + c);
+                    const f4v Y = *reinterpret_cast<const f4v*>(ly + c);
+                    const f4v Z = *reinterpret_cast<const f4v*>(lz + c);
+                    const f2v dx0 = X.xy + nqx, dy0 = Y.xy + nqy, dz0 = Z.xy + nqz;
+                    const f2v dx1 = X.zw + nqx, dy1 = Y.zw + nqy, dz1 = Z.zw + nqz;
+                    const f2v t0 = (dx0 * dx0 + dy0 * dy0 + dz0 * dz0) + nr2;   // negative: inside (the exact rule, strict)
+                    const f2v t1 = (dx1 * dx1 + dy1 * dy1 + dz1 * dz1) + nr2;
+                    m1 = __builtin_amdgcn_alignbit(m1, m0, 28);
+                    m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t0.x), 31);
+                    m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t0.y), 31);
+                    m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t1.x), 31);
+                    m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(t1.y), 31);
+                }
+                int wr = cnt;
+                cnt += __popc(m0) + __popc(m1);
+                if (!WANT_IDX && cnt >= k) { m0 = 0; m1 = 0; }   // selected later or handed on: this sum is not needed
+                // B: the set bits of m1 (the first n4 - 32 candidates of a step of more than 32), then of
+                // m0, highest first, i.e. in staging order.  A lane without bits left reads slot 0 and
+                // adds nothing.
+                auto drain = [&](uint32_t w, int n_half, int first) {
+                    while (__any(w != 0)) {
+                        const bool live = w != 0;
+                        const int lzc = __clz(w);
+                        w &= ~(0x80000000u >> (lzc & 31));
+                        const int at = live ? first + lzc + n_half - 32 : 0;   // bit b is candidate n_half - 1 - b of this half
+                        const float4 D = rec[2 * at];
+                        const float2 Wp = *reinterpret_cast<const float2*>(&rec[2 * at + 1]);
+                        const float cs = fmaf(D.x, nwx, fmaf(D.y, nwy, D.z * nwz));
+                        const float wgt = live ? fmaxf(cs, 0.f) : 0.f;
+                        sx = fmaf(D.w, wgt, sx); sy = fmaf(Wp.x, wgt, sy); sz = fmaf(Wp.y, wgt, sz);
+                        if (WANT_IDX) {
+                            if (live && wr < k) out.idx[q * k + wr] = __float_as_int(rec[2 * at + 1].z);
+                            wr += live ? 1 : 0;
+                        }
+                    }
+                };
+                if (n4 > 32) { drain(m1, n4 - 32, 0); drain(m0, 32, n4 - 32); }
+                else drain(m0, n4, 0);
             }
         }
         TK_STAMP(3)
-        const bool over = valid && (cnt >= k || (spread && Q.r2 > 0.f));
+        // Lanes that met k photons or more need a selection.  When they are many (first iterations, dense maps)
+        // the whole group is left to the selection kernel, which streams the same leaves again; when they are
+        // few they go one by one to the per-query kernel.
+        const bool streamed = mv.n > 0 && lox <= hix && !spread && fcount > 0;
+        const bool flagged = streamed && Q.r2 > 0.f && cnt >= k;
+        const bool defer_group = __popcll(__ballot(flagged)) >= sel_min_lanes;
+        const bool deferred = defer_group && flagged;
+        // a radius that was cut holds k photons or more; should a lane find fewer all the same, the
+        // per-query kernel searches its full radius
+        const bool over = valid && !deferred && (cnt >= k || (spread && Q.r2 > 0.f) || (shrunk && Q.r2 > 0.f));
         // Loads of the finished queries first, then the slot in the hand-over list (an atomic with a
         // result, which the wave waits for): the round trips run side by side instead of one after another.
-        const bool fin = valid && !over;
+        const bool fin = valid && !over && !deferred;
         float4 c4 = make_float4(0, 0, 0, 0), d4 = c4;
         float pl[5] = {0, 0, 0, 0, 0};
         const int64_t np = out.n_pixels;
@@ -1060,25 +1203,287 @@ __global__ void __launch_bounds__(256) k_gather_group(MapView mv, QueryView qv, 
             }
         }
         if (over) overflow[dst] = (int32_t)q;
-        // the per-query kernel starts from this group's leaves instead of the root
-        const bool with_leaves = !spread && mv.n > 0 && lox <= hix;
+        // the per-query kernel starts from this group's leaves instead of the root (a list it has room for)
+        const bool with_leaves = !spread && mv.n > 0 && lox <= hix && fcount <= kMaxGroupLeaves;
         if (over) gl.query_group[dst] = with_leaves ? (int32_t)g : -1;
-        if (with_leaves && __any(over)) {
-            if (lane < fcount) gl.leaves[g * kMaxGroupLeaves + lane] = front[cur][lane];
+        if ((with_leaves && __any(over)) || defer_group) {
+            for (int e = lane; e < fcount; e += 64) gl.leaves[g * kGroupLeafStride + e] = front[cur][e];
             if (lane == 0) gl.count[g] = fcount;
         }
+        flagged_sum += __popcll(__ballot(valid && Q.r2 > 0.f && (cnt >= k || spread)));
+        if (defer_group) {
+            const int64_t slot = g * 64 + lane;
+            if (slot < nq) sw.slot_cnt[slot] = deferred ? cnt : -1;
+            if (lane == 0) sw.groups[atomicAdd(sw.count, 1)] = (int32_t)g;
+        }
         cur_q = next_q; gi0 = gi1; gi1 = gi2;
-        found_sum += (unsigned long long)wave_sum_all(valid && !over ? (float)cnt : 0.f);
+        found_sum += (unsigned long long)wave_sum_all(fin ? (float)cnt : 0.f);
         TK_STAMP(4)
     }
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
     if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
+    if (sw.history && lane == 0 && flagged_sum) atomicAdd(sw.history, flagged_sum);
+    if (sw.history && blockIdx.x == 0 && threadIdx.x == 0) sw.history[1] = (int32_t)nq;
 #ifdef TK_GG_STAMPS
     // cycles per section, summed over waves: [4] wait for the group index, [5] query load + union box,
     // [6] descent, [7] candidate steps, [8] finish + hand-over (profiling builds only)
     if (out.photon_sum && lane == 0)
         for (int i = 0; i < 5; ++i) atomicAdd(out.photon_sum + 4 + i, st_sum[i]);
 #endif
+}
+
+// ------------------------------- selection kernel (groups with many lanes at k or above)
+// Works on the groups the grouped kernel has listed (SelectWork): the same 64 queries, the same leaves.
+// Two passes over the leaves as a rule: a counting pass (photons per bin of the lane's window of dist2,
+// photons below the window), a collecting pass (everything below the bin of the k-th is summed, the
+// photons of that bin are stashed, at most kSelStash, and ranked); a bin with more photons is first
+// refined by another counting pass, as long as enough lanes of the group need one.  Lanes that do not
+// come to an end this way (a k-th outside the window, many photons at one distance) go to the
+// per-query kernel like the handed-over lanes of the grouped kernel.
+template <bool WANT_IDX>
+__global__ void __launch_bounds__(256) k_gather_select(MapView mv, QueryView qv, SortedQueries qs, const uint32_t* order,
+                                                       int64_t nq, GatherOut out, int32_t* overflow, int32_t* overflow_count,
+                                                       GroupLeaves gl, SelectWork sw, int sel_min_lanes) {
+    __shared__ float s_tab[1024];
+    __shared__ __align__(16) float s_x[4][64];
+    __shared__ __align__(16) float s_y[4][64];
+    __shared__ __align__(16) float s_z[4][64];
+    __shared__ float4 s_rec[4][64][2];   // (wi.xyz, power.r) (power.g, power.b, original index, position in the tree arrays)
+    __shared__ int s_leaves[4][kGroupLeafStride];
+    __shared__ uint32_t s_sel[4][kSelBins / 2][64];   // per lane (column): histogram of a counting pass, or the stash
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int leaf_slot = lane / kLeafCap, ph = lane % kLeafCap;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int k = mv.k;
+    const int n_groups = *sw.count;
+    int* const leaves = s_leaves[wave];
+    uint32_t (*sel)[64] = s_sel[wave];
+    const float* const lx = s_x[wave];
+    const float* const ly = s_y[wave];
+    const float* const lz = s_z[wave];
+    const float4* const rec = &s_rec[wave][0][0];
+    unsigned long long found_sum = 0, staged_sum = 0;
+    for (int w = (int)blockIdx.x * 4 + wave; w < n_groups; w += (int)gridDim.x * 4) {
+        const int64_t g = sw.groups[w];
+        const int64_t slot = g * 64 + lane;
+        const bool valid = slot < nq;
+        float4 qa = make_float4(0, 0, 0, -1.f), qb = make_float4(0, 0, 0, 0);
+        int64_t q = 0;
+        int pixel = 0, cnt = -1;
+        float r2s = -1.f;
+        if (valid) {
+            qa = qs.q0[slot]; qb = qs.q1[slot];
+            q = order[slot];
+            pixel = __float_as_int(qs.pixel[slot]);
+            cnt = sw.slot_cnt[slot];
+            r2s = qs.r2s[slot];
+        }
+        const F3 qp = mk3(qa.x, qa.y, qa.z);
+        const int fcount = gl.count[g];
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < fcount; e += 64) leaves[e] = gl.leaves[g * kGroupLeafStride + e];
+        __builtin_amdgcn_wave_barrier();
+        const bool flagged = valid && cnt >= k && r2s > 0.f;
+        // 1 counting into bins, 2 collecting, 3 given up (handed on), 4 done; a handful of groups would
+        // keep a handful of waves busy for a long time: those lanes are handed on at once
+        int sel_mode = flagged ? (n_groups < sw.min_groups ? 3 : 1) : 0;
+        float sel_r2 = 0.f, ssx = 0, ssy = 0, ssz = 0;
+        auto fetch = [&](int i, float4* pp, float4* pw, uint32_t* pat) {
+            bool has = false;
+            if (i + leaf_slot < fcount) {
+                const int leaf = leaves[i + leaf_slot] - mv.nl;
+                const int64_t s0 = leaf_start(leaf, mv.n, mv.depth), e0 = leaf_start(leaf + 1, mv.n, mv.depth);
+                has = ph < (int)(e0 - s0);
+                if (has) { *pp = mv.pos4[s0 + ph]; *pw = mv.pow4[s0 + ph]; *pat = (uint32_t)(s0 + ph); }
+            }
+            return has;
+        };
+        auto stage = [&](bool has, float4 pp, float4 pw, uint32_t pat, bool with_rec) {
+            const unsigned long long staged = __ballot(has);
+            const int n_in = __popcll(staged);
+            const int n4 = (n_in + 3) & ~3;
+            __builtin_amdgcn_wave_barrier();      // the previous step has been read by every lane
+            if (has) {
+                const int at = __popcll(staged & lt_mask);
+                s_x[wave][at] = pp.x; s_y[wave][at] = pp.y; s_z[wave][at] = pp.z;
+                if (with_rec) {
+                    F3 wi = decode_dir(s_tab, __float_as_uint(pw.w));
+                    s_rec[wave][at][0] = make_float4(wi.x, wi.y, wi.z, pw.x);
+                    s_rec[wave][at][1] = make_float4(pw.y, pw.z, pp.w, __uint_as_float(pat));
+                }
+            } else {
+                // the slots up to the next multiple of four hold a position no query accepts
+                const int at = n_in + __popcll(~staged & lt_mask);
+                if (at < n4) { s_x[wave][at] = INFINITY; s_y[wave][at] = 0.f; s_z[wave][at] = 0.f; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            return n_in;
+        };
+        const f2v nqx = {-qp.x, -qp.x}, nqy = {-qp.y, -qp.y}, nqz = {-qp.z, -qp.z};
+        const float sgn = qb.w > 0.f ? 1.f : (qb.w < 0.f ? -1.f : 0.f);     // as in the grouped kernel
+        const float nwx = qb.x * sgn, nwy = qb.y * sgn, nwz = qb.z * sgn;
+        // First window: around the dist2 the k-th would have if the photons were spread evenly over the
+        // disc, from 0.4 to 1.4 times that; what lies below the window is only counted.
+        const float est = r2s * (float)k / (float)(cnt > 0 ? cnt : 1);
+        const float w_hi = fminf(1.4f * est, r2s);
+        const float w_lo = w_hi < r2s ? 0.4f * est : 0.f;
+        // bin = int(dist2 * scale) - off.  A refinement multiplies scale by kSelBins (a power of two: the
+        // product rounds the same way), so its bins nest exactly in the bin they refine.
+        float scale = flagged ? ((float)kSelBins - 0.5f) / (w_hi - w_lo) : 1.f;
+        int off = (int)(w_lo * scale), width = kSelBins, ns = 0, wr2 = 0;
+        for (int pass = 0; pass < kSelMaxPasses; ++pass) {
+            // (the lanes a third pass would be for are few as a rule: they go to the per-query kernel instead)
+            const int n_active = __popcll(__ballot(sel_mode == 1 || sel_mode == 2));
+            if (n_active == 0 || (pass >= 2 && n_active < sel_min_lanes)) break;
+            const bool any_hist = __any(sel_mode == 1), any_coll = __any(sel_mode == 2);
+            // candidates beyond this cannot fall into the window (and the bin number stays a small integer)
+            const float lim = fminf(r2s, (float)(off + width) / scale * 1.000002f);
+            const float lim_hist = sel_mode == 1 ? lim : -1.f, lim_coll = sel_mode == 2 ? lim : -1.f;
+#pragma unroll
+            for (int r = 0; r < kSelBins / 2; ++r) sel[r][lane] = 0u;
+            ns = 0;
+            int below = 0;        // candidates below the window (counting pass) / below the bin (collecting pass)
+            float4 pp = make_float4(0, 0, 0, 0), pw = pp;
+            uint32_t pat = 0;
+            bool has = fetch(0, &pp, &pw, &pat);
+            for (int i = 0; i < fcount; i += kLeavesPerStep) {
+                const int n_in = stage(has, pp, pw, pat, any_coll);
+                const int n4 = (n_in + 3) & ~3;
+                has = i + kLeavesPerStep < fcount ? fetch(i + kLeavesPerStep, &pp, &pw, &pat) : false;
+                staged_sum += (unsigned long long)n_in;
+                for (int c = 0; c < n4; c += 4) {
+                    const f4v X = *reinterpret_cast<const f4v*>(lx + c);
+                    const f4v Y = *reinterpret_cast<const f4v*>(ly + c);
+                    const f4v Z = *reinterpret_cast<const f4v*>(lz + c);
+                    const f2v dx0 = X.xy + nqx, dy0 = Y.xy + nqy, dz0 = Z.xy + nqz;
+                    const f2v dx1 = X.zw + nqx, dy1 = Y.zw + nqy, dz1 = Z.zw + nqz;
+                    const f2v t0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;   // dist2, rounded as everywhere
+                    const f2v t1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                    const float d2v[4] = {t0.x, t0.y, t1.x, t1.y};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d2 = d2v[u];
+                        const bool in_h = d2 < lim_hist, in_c = d2 < lim_coll;
+                        const int rel = (in_h || in_c) ? (int)(d2 * scale) - off : 0x40000000;
+                        below += rel < 0 ? 1 : 0;
+                        if (any_hist && in_h && (unsigned)rel < (unsigned)kSelBins)
+                            atomicAdd(&sel[rel >> 1][lane], 1u << ((rel & 1) * 16));   // the lane's own column
+                        if (any_coll && __any(in_c)) {
+                            const float4 D = rec[2 * (c + u)];
+                            const float4 E = rec[2 * (c + u) + 1];
+                            const bool inc = in_c && rel < 0;
+                            const float cs = fmaf(D.x, nwx, fmaf(D.y, nwy, D.z * nwz));
+                            const float wgt = inc ? fmaxf(cs, 0.f) : 0.f;
+                            ssx = fmaf(D.w, wgt, ssx); ssy = fmaf(E.x, wgt, ssy); ssz = fmaf(E.y, wgt, ssz);
+                            if (WANT_IDX && inc) { if (wr2 < k) out.idx[q * k + wr2] = __float_as_int(E.z); ++wr2; }
+                            if (in_c && rel == 0) {
+                                if (ns < kSelStash) sel[ns][lane] = __float_as_uint(E.w);
+                                ++ns;
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (sel_mode == 1) {
+                // the bin that holds the k-th nearest: the (k - below)-th photon of the window
+                const int need = k - below;
+                int cum = 0, bstar = -1, cstar = 0;
+#pragma unroll
+                for (int r = 0; r < kSelBins / 2; ++r) {
+                    const uint32_t v = sel[r][lane];
+                    const int c0 = (int)(v & 0xffffu), c1 = (int)(v >> 16);
+                    if (bstar < 0) { if (cum + c0 >= need) { bstar = 2 * r; cstar = c0; } else cum += c0; }
+                    if (bstar < 0) { if (cum + c1 >= need) { bstar = 2 * r + 1; cstar = c1; } else cum += c1; }
+                }
+                if (need < 1 || bstar < 0) sel_mode = 3;       // the k-th lies outside the window
+                else if (cstar <= kSelStash) { off += bstar; width = 1; sel_mode = 2; }
+                else {
+                    const long long noff = ((long long)off + bstar) * kSelBins;
+                    if (noff + kSelBins >= (1ll << 30)) sel_mode = 3;   // photons at one distance
+                    else { off = (int)noff; scale *= (float)kSelBins; }
+                }
+            } else if (sel_mode == 2) {
+                const int need = k - below;      // of the bin's photons
+                if (ns > kSelStash || need < 1 || ns < need) sel_mode = 3;   // (the counting pass saw them: does not happen)
+                else {
+                    // the photons of the bin, ranked by (dist2, photon index); the need smallest are in
+                    uint32_t pidx[kSelStash];
+#pragma unroll
+                    for (int e = 0; e < kSelStash; ++e) {
+                        pidx[e] = 0xffffffffu;
+                        if (e < ns) {
+                            const float4 p4 = mv.pos4[sel[e][lane]];
+                            sel[kSelStash + e][lane] = __float_as_uint(dist2_exact(p4.x, p4.y, p4.z, qp));
+                            pidx[e] = __float_as_uint(p4.w);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < kSelStash; ++e) {
+                        if (e < ns) {
+                            const uint32_t de = sel[kSelStash + e][lane];
+                            int rank = 0;
+#pragma unroll
+                            for (int j = 0; j < kSelStash; ++j) {
+                                if (j < ns && j != e) {
+                                    const uint32_t dj = sel[kSelStash + j][lane];
+                                    rank += (dj < de || (dj == de && pidx[j] < pidx[e])) ? 1 : 0;
+                                }
+                            }
+                            if (rank < need) {
+                                const float4 w4 = mv.pow4[sel[e][lane]];
+                                const F3 wi = decode_dir(s_tab, __float_as_uint(w4.w));
+                                const float cs = fmaf(wi.x, nwx, fmaf(wi.y, nwy, wi.z * nwz));
+                                const float wgt = fmaxf(cs, 0.f);
+                                ssx = fmaf(w4.x, wgt, ssx); ssy = fmaf(w4.y, wgt, ssy); ssz = fmaf(w4.z, wgt, ssz);
+                                sel_r2 = fmaxf(sel_r2, __uint_as_float(de));
+                                if (WANT_IDX) { if (wr2 < k) out.idx[q * k + wr2] = (int32_t)pidx[e]; ++wr2; }
+                            }
+                        }
+                    }
+                    sel_mode = 4;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool fin = sel_mode == 4;
+        const bool over = flagged && !fin;
+        float4 c4 = make_float4(0, 0, 0, 0), d4 = c4;
+        float pl[5] = {0, 0, 0, 0, 0};
+        const int64_t np = out.n_pixels;
+        const int fl = out.which == 0 ? 6 : 3, pn = out.which == 0 ? 10 : 9, pr = out.which == 0 ? 12 : 11;
+        if (fin) {
+            c4 = qv.q2[q]; d4 = qv.q3[q];
+            if (out.planes) {
+                const float* P = out.planes;
+                pl[0] = P[fl * np + pixel]; pl[1] = P[(fl + 1) * np + pixel]; pl[2] = P[(fl + 2) * np + pixel];
+                pl[3] = P[pn * np + pixel]; pl[4] = P[pr * np + pixel];
+            }
+        }
+        const int dst = wave_append(overflow_count, over);
+        if (fin) {
+            const F3 est3 = mul3(mk3(ssx, ssy, ssz), mk3(d4.x, d4.y, d4.z));
+            if (out.flux) { out.flux[3 * q] = est3.x; out.flux[3 * q + 1] = est3.y; out.flux[3 * q + 2] = est3.z; }
+            if (out.found) out.found[q] = k;
+            if (out.r2out) out.r2out[q] = sel_r2;
+            if (out.planes) {
+                const F3 lind = mul3(mk3(c4.x, c4.y, c4.z), est3);
+                pixel_update(&pl[0], &pl[1], &pl[2], &pl[3], &pl[4], lind, k, sel_r2);
+                float* P = out.planes;
+                P[fl * np + pixel] = pl[0]; P[(fl + 1) * np + pixel] = pl[1]; P[(fl + 2) * np + pixel] = pl[2];
+                P[pn * np + pixel] = pl[3]; P[pr * np + pixel] = pl[4];
+            }
+        }
+        if (over) {
+            overflow[dst] = (int32_t)q;
+            gl.query_group[dst] = fcount <= kMaxGroupLeaves ? (int32_t)g : -1;
+        }
+        found_sum += (unsigned long long)wave_sum_all(fin ? (float)k : 0.f);
+    }
+    if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
+    if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
 }
 
 // Hilbert key of every query inside the root box of the tree.  Consecutive
@@ -1170,6 +1575,14 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
     if (!rc) rc = m->counters.ensure(512);
     if (!rc) rc = m->totals.ensure(128);
     if (!rc && hipMemset(m->totals.p, 0, 128) != hipSuccess) { set_error("map_create: memset failed"); rc = TKHIP_E_HIP; }
+    // ints 64, 65 of the counters: gathers of the last launch that met k photons, and all of them.  No launch yet:
+    // as if all had (radii are bounded before the first gather)
+    const int32_t history0[4] = {1, 1, 1, 1};
+    if (!rc && (hipMemset(m->counters.p, 0, 512) != hipSuccess ||
+                hipMemcpy(m->counters.as<int32_t>() + 64, history0, 16, hipMemcpyHostToDevice) != hipSuccess)) {
+        set_error("map_create: counter set-up failed");
+        rc = TKHIP_E_HIP;
+    }
     if (!rc && (hipEventCreate(&m->ev_begin) != hipSuccess || hipEventCreate(&m->ev_end) != hipSuccess)) {
         set_error("map_create: hipEventCreate failed");
         rc = TKHIP_E_HIP;
@@ -1184,7 +1597,7 @@ void map_destroy(tkhip_map* m) {
     if (!m) return;
     DevBuf* bufs[] = {&m->in_pos, &m->in_pow, &m->in_dir, &m->pos4, &m->pow4, &m->node_box, &m->node_axis, &m->clip_box, &m->idx_a, &m->idx_b, &m->key_a, &m->key_b, &m->root_box, &m->q_order,
                       &m->q_keys_a, &m->q_keys_b, &m->q_vals_a, &m->q_sorted, &m->overflow, &m->counters, &m->prim_temp,
-                      &m->overflow_group, &m->group_leaves, &m->group_leaf_count};
+                      &m->overflow_group, &m->group_leaves, &m->group_leaf_count, &m->sel_groups, &m->sel_cnt, &m->q_r2s};
     for (DevBuf* b : bufs) b->release();
     m->totals.release();
     if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
@@ -1304,6 +1717,7 @@ tkd::MapView tkhip_map::view() const {
     v.pow4 = pow4.as<float4>();
     v.node_box = node_box.as<float4>();
     v.dirtab = ctx->b_dirtab.as<float>();
+    v.keys = (tree_mode == 0 && n > 0) ? key_b.as<uint32_t>() : nullptr;
     v.n = (int32_t)n;
     v.nl = nl;
     v.depth = depth;
@@ -1328,8 +1742,11 @@ int map_reserve_queries(tkhip_map* m, int64_t nq) {
     TK_TRY(m->q_sorted.ensure((size_t)nq * 32));
     TK_TRY(m->overflow.ensure((size_t)nq * 4));
     TK_TRY(m->overflow_group.ensure((size_t)nq * 4));
-    TK_TRY(m->group_leaves.ensure((size_t)((nq + 63) / 64) * kMaxGroupLeaves * 4));
+    TK_TRY(m->group_leaves.ensure((size_t)((nq + 63) / 64) * kGroupLeafStride * 4));
     TK_TRY(m->group_leaf_count.ensure((size_t)((nq + 63) / 64) * 4));
+    TK_TRY(m->sel_groups.ensure((size_t)((nq + 63) / 64) * 4));
+    TK_TRY(m->sel_cnt.ensure((size_t)nq * 4));
+    TK_TRY(m->q_r2s.ensure((size_t)nq * 4));
     const size_t nb = query_bucket_count(nq);
     size_t scan_bytes = 0;
     TK_TRY(exclusive_scan_i32_temp_bytes(nb + 1, &scan_bytes));
@@ -1359,6 +1776,11 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         sc.q_vals_a = m->q_vals_a.as<uint32_t>(); sc.q_order = m->q_order.as<uint32_t>();
         sc.overflow = m->overflow.as<int32_t>(); sc.overflow_group = m->overflow_group.as<int32_t>();
         sc.group_leaves = m->group_leaves.as<int32_t>(); sc.group_leaf_count = m->group_leaf_count.as<int32_t>();
+        sc.sel_groups = m->sel_groups.as<int32_t>(); sc.sel_cnt = m->sel_cnt.as<int32_t>(); sc.q_r2s = m->q_r2s.as<float>();
+        // two pairs of ints that outlive the gather, taken in turns: this launch counts into one and reads the last launch's
+        sc.history = m->counters.as<int32_t>() + 64 + 2 * m->history_turn;
+        sc.history_last = m->counters.as<int32_t>() + 64 + 2 * (1 - m->history_turn);
+        m->history_turn = 1 - m->history_turn;
         sc.counter = m->counters.as<int32_t>();
         sc.q_sorted = m->q_sorted.as<float4>();
         sc.sort_temp = m->prim_temp.p; sc.sort_temp_bytes = m->prim_temp.bytes;
@@ -1378,6 +1800,23 @@ static int group_grid_blocks(int device) {
         if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gather_group<false>, 256, 0) != hipSuccess || per_cu < 1)
             cached[device] = 256 * 8;
+        else
+            cached[device] = std::max(prop.multiProcessorCount, 1) * per_cu;
+    }
+    return cached[device];
+}
+
+static int select_grid_blocks(int device) {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64) return 256 * 4;
+    if (cached[device] == 0) {
+        hipDeviceProp_t prop{};
+        int per_cu = 0;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gather_select<false>, 256, 0) != hipSuccess || per_cu < 1)
+            cached[device] = 256 * 4;
         else
             cached[device] = std::max(prop.multiProcessorCount, 1) * per_cu;
     }
@@ -1422,24 +1861,50 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     k_query_rank<<<divup(nq, 256), 256, 0, s>>>(qv, nq, sc.q_keys_a, sc.q_vals_a, bucket_start, sc.q_keys_b, placed_index,
                                                 sc.q_order);
     TK_LAUNCH_CHECK();
-    k_sort_queries<<<divup(nq, 256), 256, 0, s>>>(qv, sc.q_order, nq, sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<float*>(sc.q_keys_a));
+    k_sort_queries<<<divup(nq, 256), 256, 0, s>>>(qv, sc.q_order, nq, sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<float*>(sc.q_keys_a),
+                                                  sc.q_r2s);
     TK_LAUNCH_CHECK();
+    // radii far larger than the photon spacing are cut first (the kernel ends at once when the last gather
+    // of this map met k photons in few places); level: the deepest whose nodes all hold k photons or more
+    // (a node of level L holds at least n >> L)
+    if (m->n >= m->k) {
+        int level = 0;
+        while (level < m->depth && (m->n >> (level + 1)) >= m->k) ++level;
+        level = std::max(level - 1, 0);   // one level higher (2 k photons): the k nearest of a larger node are nearer
+        k_query_bound<<<divup(nq, 256), 256, 0, s>>>(m->view(), nq, sc.q_sorted, sc.q_r2s, sc.history_last, level);
+        TK_LAUNCH_CHECK();
+    }
+    if (sc.history) TK_HIP(hipMemsetAsync(sc.history, 0, 8, s));
     int32_t* ocount = sc.counter;          // the hand-over count
     // the grid: as many waves as the GPU holds at once (fewer waves with the same number of groups
     // each were no faster: 0.24 against 0.23 ms per launch)
     const int64_t groups = (nq + 63) / 64;
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), group_grid_blocks(m->ctx->device));
-    TK_HIP(hipMemsetAsync(ocount, 0, 4, s));
+    int32_t* scount = sc.counter + 16;     // groups left to the selection kernel
+    TK_HIP(hipMemsetAsync(ocount, 0, 128, s));
     TK_TRY(map_flush_timing(m));
     TK_HIP(hipEventRecord(m->ev_begin, s));
     const GroupLeaves gl{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
-    const SortedQueries qs{sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<const float*>(sc.q_keys_a)};   // the keys are done with
+    // (the two thresholds can be forced from the environment: tests run every gather through the selection kernel)
+    static const int sel_min_env = getenv("TKHIP_SEL_MIN") ? atoi(getenv("TKHIP_SEL_MIN")) : 0;
+    const int sel_min = sel_min_env > 0 ? sel_min_env : (m->n > kSelLargeMap ? kSelMinLanesLarge : kSelMinLanes);
+    static const int sel_groups = getenv("TKHIP_SEL_GROUPS") ? atoi(getenv("TKHIP_SEL_GROUPS")) : kSelMinGroups;
+    const SortedQueries qs{sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<const float*>(sc.q_keys_a), sc.q_r2s};   // the keys are done with
+    const SelectWork sw{sc.sel_groups, scount, sc.sel_cnt, sc.history, sc.history_last, sel_groups};
     if (out.idx)
-        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl);
+        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
     else
-        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl);
+        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
     TK_LAUNCH_CHECK();
     TK_HIP(hipEventRecord(m->ev_end, s));
+    // the groups with many lanes at k or above (their number is known to the device only: the waves of a
+    // grid that fills the GPU once share them out)
+    const int sel_blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), select_grid_blocks(m->ctx->device));
+    if (out.idx)
+        k_gather_select<true><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+    else
+        k_gather_select<false><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+    TK_LAUNCH_CHECK();
     m->ev_pending = true;
     m->group_queries += nq;
     if (timed) {
@@ -1661,8 +2126,13 @@ int tkhip_map_gather_static(tkhip_map* m, int64_t nq, const float* p, const floa
     sc.q_sorted = reinterpret_cast<float4*>(take(Q * 32));
     sc.overflow = reinterpret_cast<int32_t*>(take(Q * 4));
     sc.overflow_group = reinterpret_cast<int32_t*>(take(Q * 4));
-    sc.group_leaves = reinterpret_cast<int32_t*>(take((Q / 64) * kMaxGroupLeaves * 4));
+    sc.group_leaves = reinterpret_cast<int32_t*>(take((Q / 64) * kGroupLeafStride * 4));
     sc.group_leaf_count = reinterpret_cast<int32_t*>(take((Q / 64) * 4));
+    sc.sel_groups = reinterpret_cast<int32_t*>(take((Q / 64) * 4));
+    sc.sel_cnt = reinterpret_cast<int32_t*>(take(Q * 4));
+    sc.q_r2s = reinterpret_cast<float*>(take(Q * 4));
+    sc.history = nullptr;      // the array is shared by every map of the GPU: no history, the radii are always bounded
+    sc.history_last = nullptr;
     sc.counter = reinterpret_cast<int32_t*>(take(512));
     TK_REQUIRE(at < (size_t)TKHIP_STATIC_SCRATCH_BYTES, TKHIP_E_LIMIT, "tkhip_map_gather_static: scratch layout exceeds the array");
     sc.sort_temp = base + at;
