@@ -37,9 +37,9 @@ struct GatherScratch {
     int32_t *overflow, *overflow_group, *group_leaves, *group_leaf_count;
     int32_t *sel_groups, *sel_cnt;   // groups left to the selection kernel; per query slot: photons met
     float* q_r2s;                    // per query slot: the radius^2 to search with (the query's own or a smaller bound)
-    int32_t* history;                // 2 ints that outlive the gather: queries of this launch that met k photons, all queries (or null)
-    const int32_t* history_last;     // the same of the map's last launch (or null)
-    int32_t* counter;            // 32 ints, cleared per gather: [0] the hand-over count, [16] the selection kernel's groups
+    int heavy;                       // many gathers of the map's last launch met k photons (or no launch yet): radii are cut first
+    int track;                       // count the gathers of this launch that meet k photons (counter[24]) for the next decision
+    int32_t* counter;            // 32 ints, cleared per gather: [0] the hand-over count, [16] the selection kernel's groups, [24] gathers that met k photons
     void* sort_temp;
     size_t sort_temp_bytes;
 };
@@ -65,7 +65,10 @@ struct tkhip_map {
     int nl = 0, depth = 0;
     tkd::DevBuf in_pos, in_pow, in_dir;            // storage order: float3, float3, u16
     tkd::DevBuf pos4, pow4, node_box, node_axis, clip_box;
-    int history_turn = 0;           // which of the two history pairs in `counters` the next gather counts into
+    int32_t* met_k_host = nullptr;  // pinned: gathers of the last launch that met k photons or more
+    int64_t met_k_queries = 0;      // ... of this many
+    bool met_k_pending = false;
+    hipEvent_t ev_met_k = nullptr;  // recorded behind the copy into met_k_host
     int tree_mode = 0;              // 0: one sort along a Hilbert curve; 1: median splits, one sort per level
     tkd::DevBuf idx_a, idx_b, key_a, key_b, root_box;
     tkd::DevBuf q_order, q_keys_a, q_keys_b, q_vals_a, q_sorted, overflow, counters;

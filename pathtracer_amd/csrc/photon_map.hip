@@ -543,9 +543,9 @@ struct SelectWork {
     int32_t* groups;      // group numbers
     int32_t* count;       // how many
     int32_t* slot_cnt;    // per query slot (curve order) of such a group: photons inside the search radius, -1: nothing to select
-    int32_t* history;     // [0] queries of this launch that met k photons or more, [1] all of them (or null)
-    const int32_t* history_last;   // the same of the map's last launch (or null: as if all had)
+    int32_t* met_k;       // counts the queries of this launch that met k photons or more (or null)
     int min_groups;       // fewer groups than this cannot fill the GPU: their lanes go to the per-query kernel
+    int heavy;            // many gathers of the map's last launch met k photons: radii have been cut, long leaf lists are taken
 };
 
 template <int EPL>
@@ -833,13 +833,12 @@ __global__ void k_sort_queries(QueryView qv, const uint32_t* order, int64_t nq, 
 // k-th smallest dist2 among the photons of that node bounds the dist2 of the k-th nearest photon of the
 // whole map from above, and the k nearest inside a sphere that holds k photons or more are the k nearest
 // inside any larger one.  The k-th smallest is taken to the upper edge of its bin among kSelBins bins of
-// dist2 up to the radius (or the node's far corner when that is nearer).  The kernel ends at once when few
-// gathers of the map's last launch met k photons (history[0] of history[1]): then radii are small already.
+// dist2 up to the radius (or the node's far corner when that is nearer).  The host launches it while many
+// gathers of the map's last launch met k photons; otherwise radii are small already.
 constexpr int kSelBins = 32;        // histogram bins of a lane (two 16-bit counters to a word: kSelBins / 2 words)
 __global__ void __launch_bounds__(256) k_query_bound(MapView mv, int64_t nq, const float4* q0s, float* r2s,
-                                                     const int32_t* history, int level) {
+                                                     int level) {
     __shared__ uint32_t s_hist[kSelBins / 2][256];
-    if (history && (int64_t)history[0] * 4 < (int64_t)history[1]) return;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const float4 a = q0s[i];
@@ -918,6 +917,8 @@ constexpr int kSelMinLanesLarge = 32;      // ... in a map of more than kSelLarg
 constexpr int64_t kSelLargeMap = 1 << 20;  //     the per-query kernel pays for that query by query)
 constexpr int kSelMinGroups = 2048; // ... and so do all groups when they are fewer than this (half the waves a GPU holds)
 constexpr int kSelMaxPasses = 5;
+constexpr int kSelHeavyPercent = 75;       // share of a map's last launch that met k photons from which radii are cut and
+constexpr int kSelHeavyPercentLarge = 25;  // long leaf lists taken; in a map of more than kSelLargeMap photons
 static_assert(kSelStash <= kSelBins / 2, "the stash of a lane reuses the words of its histogram");
 
 template <bool WANT_IDX>
@@ -943,8 +944,7 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
     const float4 root0 = mv.node_box[2], root1 = mv.node_box[3];   // box of the whole map (heap node 1)
     unsigned long long found_sum = 0, staged_sum = 0;
     int flagged_sum = 0;     // queries of this wave that met k photons or more (what the next launch goes by)
-    // many gathers of the map's last launch met k photons or more
-    const bool heavy = sw.history_last == nullptr || (int64_t)sw.history_last[0] * 4 >= (int64_t)sw.history_last[1];
+    const bool heavy = sw.heavy != 0;
     // Groups are handed out one at a time: the waves of the grid (sized to what the GPU holds at once)
     // stay busy until the last group is taken.  Two group indices are kept ahead of the one being worked
     // on, and the queries of the next group are loaded while the current one is worked on, so that a
@@ -1222,8 +1222,7 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
     }
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
     if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
-    if (sw.history && lane == 0 && flagged_sum) atomicAdd(sw.history, flagged_sum);
-    if (sw.history && blockIdx.x == 0 && threadIdx.x == 0) sw.history[1] = (int32_t)nq;
+    if (sw.met_k && lane == 0 && flagged_sum) atomicAdd(sw.met_k, flagged_sum);
 #ifdef TK_GG_STAMPS
     // cycles per section, summed over waves: [4] wait for the group index, [5] query load + union box,
     // [6] descent, [7] candidate steps, [8] finish + hand-over (profiling builds only)
@@ -1575,12 +1574,9 @@ int map_create(tkhip_ctx* ctx, int64_t capacity, int k, tkhip_map** out) {
     if (!rc) rc = m->counters.ensure(512);
     if (!rc) rc = m->totals.ensure(128);
     if (!rc && hipMemset(m->totals.p, 0, 128) != hipSuccess) { set_error("map_create: memset failed"); rc = TKHIP_E_HIP; }
-    // ints 64, 65 of the counters: gathers of the last launch that met k photons, and all of them.  No launch yet:
-    // as if all had (radii are bounded before the first gather)
-    const int32_t history0[4] = {1, 1, 1, 1};
-    if (!rc && (hipMemset(m->counters.p, 0, 512) != hipSuccess ||
-                hipMemcpy(m->counters.as<int32_t>() + 64, history0, 16, hipMemcpyHostToDevice) != hipSuccess)) {
-        set_error("map_create: counter set-up failed");
+    // where the device reports how many gathers of a launch met k photons (read when the next launch is set up)
+    if (!rc && (hipHostMalloc((void**)&m->met_k_host, 64) != hipSuccess || hipEventCreate(&m->ev_met_k) != hipSuccess)) {
+        set_error("map_create: pinned counter set-up failed");
         rc = TKHIP_E_HIP;
     }
     if (!rc && (hipEventCreate(&m->ev_begin) != hipSuccess || hipEventCreate(&m->ev_end) != hipSuccess)) {
@@ -1602,6 +1598,8 @@ void map_destroy(tkhip_map* m) {
     m->totals.release();
     if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
     if (m->ev_end) (void)hipEventDestroy(m->ev_end);
+    if (m->ev_met_k) (void)hipEventDestroy(m->ev_met_k);
+    if (m->met_k_host) (void)hipHostFree(m->met_k_host);
     delete m;
 }
 
@@ -1777,10 +1775,16 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
         sc.overflow = m->overflow.as<int32_t>(); sc.overflow_group = m->overflow_group.as<int32_t>();
         sc.group_leaves = m->group_leaves.as<int32_t>(); sc.group_leaf_count = m->group_leaf_count.as<int32_t>();
         sc.sel_groups = m->sel_groups.as<int32_t>(); sc.sel_cnt = m->sel_cnt.as<int32_t>(); sc.q_r2s = m->q_r2s.as<float>();
-        // two pairs of ints that outlive the gather, taken in turns: this launch counts into one and reads the last launch's
-        sc.history = m->counters.as<int32_t>() + 64 + 2 * m->history_turn;
-        sc.history_last = m->counters.as<int32_t>() + 64 + 2 * (1 - m->history_turn);
-        m->history_turn = 1 - m->history_turn;
+        // Many gathers of the map's last launch met k photons (or there was none yet): radii are cut first and long
+        // leaf lists taken.  The count of that launch has arrived long ago; the wait is for form.
+        static const int heavy_pct_env = getenv("TKHIP_HEAVY_PCT") ? atoi(getenv("TKHIP_HEAVY_PCT")) : 0;
+        const int heavy_pct = heavy_pct_env > 0 ? heavy_pct_env : (m->n > kSelLargeMap ? kSelHeavyPercentLarge : kSelHeavyPercent);
+        sc.heavy = 1;
+        if (m->met_k_pending) {
+            TK_HIP(hipEventSynchronize(m->ev_met_k));
+            sc.heavy = (int64_t)m->met_k_host[0] * 100 >= m->met_k_queries * heavy_pct ? 1 : 0;
+        }
+        sc.track = 1;
         sc.counter = m->counters.as<int32_t>();
         sc.q_sorted = m->q_sorted.as<float4>();
         sc.sort_temp = m->prim_temp.p; sc.sort_temp_bytes = m->prim_temp.bytes;
@@ -1864,17 +1868,15 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     k_sort_queries<<<divup(nq, 256), 256, 0, s>>>(qv, sc.q_order, nq, sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<float*>(sc.q_keys_a),
                                                   sc.q_r2s);
     TK_LAUNCH_CHECK();
-    // radii far larger than the photon spacing are cut first (the kernel ends at once when the last gather
-    // of this map met k photons in few places); level: the deepest whose nodes all hold k photons or more
-    // (a node of level L holds at least n >> L)
-    if (m->n >= m->k) {
+    // radii far larger than the photon spacing are cut first; level: the deepest whose nodes all hold k photons
+    // or more (a node of level L holds at least n >> L)
+    if (sc.heavy && m->n >= m->k) {
         int level = 0;
         while (level < m->depth && (m->n >> (level + 1)) >= m->k) ++level;
         level = std::max(level - 1, 0);   // one level higher (2 k photons): the k nearest of a larger node are nearer
-        k_query_bound<<<divup(nq, 256), 256, 0, s>>>(m->view(), nq, sc.q_sorted, sc.q_r2s, sc.history_last, level);
+        k_query_bound<<<divup(nq, 256), 256, 0, s>>>(m->view(), nq, sc.q_sorted, sc.q_r2s, level);
         TK_LAUNCH_CHECK();
     }
-    if (sc.history) TK_HIP(hipMemsetAsync(sc.history, 0, 8, s));
     int32_t* ocount = sc.counter;          // the hand-over count
     // the grid: as many waves as the GPU holds at once (fewer waves with the same number of groups
     // each were no faster: 0.24 against 0.23 ms per launch)
@@ -1887,10 +1889,11 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     const GroupLeaves gl{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
     // (the two thresholds can be forced from the environment: tests run every gather through the selection kernel)
     static const int sel_min_env = getenv("TKHIP_SEL_MIN") ? atoi(getenv("TKHIP_SEL_MIN")) : 0;
-    const int sel_min = sel_min_env > 0 ? sel_min_env : (m->n > kSelLargeMap ? kSelMinLanesLarge : kSelMinLanes);
+    // (while few gathers meet k photons no group is left to the selection kernel: it is not even launched)
+    const int sel_min = !sc.heavy ? 65 : sel_min_env > 0 ? sel_min_env : (m->n > kSelLargeMap ? kSelMinLanesLarge : kSelMinLanes);
     static const int sel_groups = getenv("TKHIP_SEL_GROUPS") ? atoi(getenv("TKHIP_SEL_GROUPS")) : kSelMinGroups;
     const SortedQueries qs{sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<const float*>(sc.q_keys_a), sc.q_r2s};   // the keys are done with
-    const SelectWork sw{sc.sel_groups, scount, sc.sel_cnt, sc.history, sc.history_last, sel_groups};
+    const SelectWork sw{sc.sel_groups, scount, sc.sel_cnt, sc.track ? sc.counter + 24 : nullptr, sel_groups, sc.heavy};
     if (out.idx)
         k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
     else
@@ -1900,7 +1903,8 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     // the groups with many lanes at k or above (their number is known to the device only: the waves of a
     // grid that fills the GPU once share them out)
     const int sel_blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), select_grid_blocks(m->ctx->device));
-    if (out.idx)
+    if (!sc.heavy) {}
+    else if (out.idx)
         k_gather_select<true><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
     else
         k_gather_select<false><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
@@ -1913,6 +1917,12 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     }
     wave_all(sc.overflow, ocount, nq, gl);
     TK_LAUNCH_CHECK();
+    if (sc.track) {
+        TK_HIP(hipMemcpyAsync(m->met_k_host, sc.counter + 24, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(hipEventRecord(m->ev_met_k, s));
+        m->met_k_pending = true;
+        m->met_k_queries = nq;
+    }
     if (timed) {
         int32_t oc = 0;
         TK_HIP(hipMemcpyAsync(&oc, ocount, 4, hipMemcpyDeviceToHost, s));
@@ -2131,8 +2141,8 @@ int tkhip_map_gather_static(tkhip_map* m, int64_t nq, const float* p, const floa
     sc.sel_groups = reinterpret_cast<int32_t*>(take((Q / 64) * 4));
     sc.sel_cnt = reinterpret_cast<int32_t*>(take(Q * 4));
     sc.q_r2s = reinterpret_cast<float*>(take(Q * 4));
-    sc.history = nullptr;      // the array is shared by every map of the GPU: no history, the radii are always bounded
-    sc.history_last = nullptr;
+    sc.heavy = 1;      // the array is shared by every map of the GPU: no history, the radii are always bounded
+    sc.track = 0;
     sc.counter = reinterpret_cast<int32_t*>(take(512));
     TK_REQUIRE(at < (size_t)TKHIP_STATIC_SCRATCH_BYTES, TKHIP_E_LIMIT, "tkhip_map_gather_static: scratch layout exceeds the array");
     sc.sort_temp = base + at;
