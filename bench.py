@@ -297,7 +297,7 @@ def main():
         # instrumented iterations: every gather's 56 B query + 26 B per photon found + 40 B pixel slice.
         gather_bytes = 96.0 * (ng + nc) + 26.0 * phot
         gp = gather_bytes / (ms_gather * 1e-3) / 1e9 if ms_gather > 0 else 0.0
-        out["roofline_gather_phase"] = {"bound": "hbm", "kernels": "k_query_curve, radix sort, k_sort_queries, k_gather_group, k_gather_wave (both maps)",
+        out["roofline_gather_phase"] = {"bound": "hbm", "kernels": "k_query_bucket / place / rank, k_sort_queries, k_gather_group, k_gather_wave (both maps); in the first iterations also k_query_bound and k_gather_select",
                                         "achieved": gp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gp / HBM_PEAK_GBS,
                                         "ms": ms_gather, "algorithmic_bytes": gather_bytes,
                                         "gathers": ng + nc, "photons_found": phot}
