@@ -332,6 +332,35 @@ TKD bool photon_on_hit(const PhotonArgs& a, int slot, int bounce, PhotonPath& P,
     P.d = wi;
     return bounce + 1 < a.depth;
 }
+// Whether a ray can meet a specular object at all: slab test against the padded bounds of each (a ray
+// parallel to a slab and outside of it yields an empty or NaN interval and counts as passing by only
+// when it is empty beyond doubt).
+TKD bool may_hit_specular(const DScene& sc, F3 o, F3 d) {
+    if (sc.n_spec_boxes < 0) return true;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    for (int b = 0; b < sc.n_spec_boxes; ++b) {
+        const float* B = sc.spec_box[b];
+        float t0 = 0.f, t1 = INFINITY;
+        bool miss = false;
+        {
+            const float a0 = (B[0] - o.x) * ix, a1 = (B[3] - o.x) * ix;
+            if (d.x != 0.f) { t0 = fmaxf(t0, fminf(a0, a1)); t1 = fminf(t1, fmaxf(a0, a1)); }
+            else miss = miss || o.x < B[0] || o.x > B[3];
+        }
+        {
+            const float a0 = (B[1] - o.y) * iy, a1 = (B[4] - o.y) * iy;
+            if (d.y != 0.f) { t0 = fmaxf(t0, fminf(a0, a1)); t1 = fminf(t1, fmaxf(a0, a1)); }
+            else miss = miss || o.y < B[1] || o.y > B[4];
+        }
+        {
+            const float a0 = (B[2] - o.z) * iz, a1 = (B[5] - o.z) * iz;
+            if (d.z != 0.f) { t0 = fmaxf(t0, fminf(a0, a1)); t1 = fminf(t1, fmaxf(a0, a1)); }
+            else miss = miss || o.z < B[2] || o.z > B[5];
+        }
+        if (!miss && t0 <= t1 * 1.0001f) return true;
+    }
+    return false;
+}
 template <int KIND, class STACK>
 TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, bool* specular, STACK stk) {
     const Hit h = trace_ray(a.sc, P.o, P.d, 1.7976931348623157e308, false, stk);
@@ -389,6 +418,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
     if (i < B) {
         if (KIND == 1) a.rec_count[i] = 0;
         alive = photon_emit<KIND>(a, (int)i, P);
+        // a path for the caustic map whose first ray passes by every specular object ends at a diffuse
+        // surface or nowhere and stores nothing: it is counted as shot and not traced
+        if (KIND == 1 && alive && !may_hit_specular(a.sc, P.o, P.d)) alive = false;
         if (alive) {
             traced = 1;
             alive = photon_step<KIND>(a, (int)i, 0, P, &specular, stk);

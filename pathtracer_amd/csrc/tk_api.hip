@@ -309,6 +309,30 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     sc.n_tris = n_tris; sc.n_spheres = n_spheres; sc.n_lights = n_lights;
     sc.n_nodes = n_nodes;
     for (int a = 0; a < 3; ++a) { sc.bmin[a] = bmin[a]; sc.bmax[a] = bmax[a]; }
+    // bounds of the specular objects, padded by a ten-thousandth of the scene's extent
+    sc.n_spec_boxes = 0;
+    float pad = 0.f;
+    for (int a = 0; a < 3; ++a) pad = std::max(pad, (bmax[a] - bmin[a]) * 1e-4f);
+    for (int o = 0; o < n_objects && sc.n_spec_boxes >= 0; ++o) {
+        const TkObject& ob = objects[o];
+        if (materials[ob.material].type == TK_DIFFUSE || ob.count == 0) continue;
+        if (sc.n_spec_boxes == kMaxSpecBoxes) { sc.n_spec_boxes = -1; break; }
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < ob.count; ++i)
+            for (int a = 0; a < 3; ++a) {
+                if (ob.kind == 0) {
+                    const TkTriangle& t = tris[ob.first + i];
+                    lo[a] = std::min(lo[a], std::min(t.v0[a], std::min(t.v1[a], t.v2[a])));
+                    hi[a] = std::max(hi[a], std::max(t.v0[a], std::max(t.v1[a], t.v2[a])));
+                } else {
+                    const TkSphere& sp = spheres[ob.first + i];
+                    lo[a] = std::min(lo[a], sp.center[a] - sp.radius);
+                    hi[a] = std::max(hi[a], sp.center[a] + sp.radius);
+                }
+            }
+        float* b = sc.spec_box[sc.n_spec_boxes++];
+        for (int a = 0; a < 3; ++a) { b[a] = lo[a] - pad; b[3 + a] = hi[a] + pad; }
+    }
     ctx->has_scene = true;
     return TKHIP_OK;
 }

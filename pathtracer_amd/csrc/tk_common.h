@@ -123,7 +123,13 @@ struct DScene {
     const float* light_cdf;
     int32_t n_tris, n_spheres, n_lights, n_nodes;
     float bmin[3], bmax[3];
+    // Padded bounds of the objects with a specular material (min xyz, max xyz), n_spec_boxes of them; -1:
+    // more such objects than kMaxSpecBoxes, no statement.  A light path for the caustic map that misses all
+    // of them cannot meet a specular surface first and so stores nothing.
+    int32_t n_spec_boxes;
+    float spec_box[8][6];
 };
+constexpr int kMaxSpecBoxes = 8;
 
 struct DCamera {
     float c2w[16];
