@@ -1,6 +1,6 @@
-// tk_prims.hip — device-wide radix sort (rocPRIM), kept in a translation unit
-// of its own because the headers are heavy to compile.  (The prefix sum is in
-// tk_scan.hip.)
+// tk_prims.hip — device-wide radix sort and (for small inputs) prefix scan of
+// rocPRIM, kept in a translation unit of their own because the headers are
+// heavy to compile.  The prefix sum the passes call is in tk_scan.hip.
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -53,6 +53,25 @@ int sort_pairs_u32_reserve(DevBuf& temp, size_t n, int end_bit) {
     uint32_t* none = nullptr;
     TK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, none, none, none, none, n, 0, end_bit, (hipStream_t) nullptr));
     return temp.ensure(bytes);
+}
+
+// The library's scan, for the sizes tk_scan.hip leaves to it.
+int library_scan_i32_temp_bytes(size_t n, size_t* bytes) {
+    *bytes = 0;
+    if (n == 0) return TKHIP_OK;
+    const int32_t* none = nullptr;
+    int32_t* out = nullptr;
+    TK_HIP(rocprim::exclusive_scan(nullptr, *bytes, none, out, 0, n, rocprim::plus<int32_t>(), (hipStream_t) nullptr));
+    return TKHIP_OK;
+}
+
+int library_scan_i32_in(hipStream_t stream, void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n) {
+    if (n == 0) return TKHIP_OK;
+    size_t bytes = 0;
+    TK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int32_t>(), stream));
+    TK_REQUIRE(bytes <= temp_bytes, TKHIP_E_LIMIT, "scan of %zu values needs %zu bytes of scratch, %zu given", n, bytes, temp_bytes);
+    TK_HIP(rocprim::exclusive_scan(temp, bytes, in, out, 0, n, rocprim::plus<int32_t>(), stream));
+    return TKHIP_OK;
 }
 
 }  // namespace tkd
