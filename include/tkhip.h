@@ -501,6 +501,17 @@ int tkhip_stratified_samples(tkhip_ctx* ctx, int64_t n, const int32_t* px, const
 int tkhip_spawn_rays(tkhip_ctx* ctx, int64_t n, const float* p, const float* perr, const float* nrm,
                      const float* w, const float* target, float* org, float* org_to, float* dir_to);
 
+/* Scene::uniformSampleOneLight (src/core/Scene.cpp:43-61: AreaLight::sample_Li,
+ * src/Light.cpp:24-39, the shadow ray of Intersection::spawnRayTo(other),
+ * src/Intersection.hpp:40-48, Scene::intersectP, Material::f) at the first hit
+ * of each of n rays.  u holds, per ray, the four numbers the call takes from its
+ * sampler, in the order it takes them: get1D (which light), get2D (point on the
+ * light), get1D (which triangle of the light's mesh).  prim is the hit as in
+ * tkhip_trace_rays, ld the returned spectrum (black for a miss).  Host arrays:
+ * org, dir float[3n], u float[4n] -> prim int32[n], ld float[3n]. */
+int tkhip_sample_one_light(tkhip_ctx* ctx, int64_t n, const float* org, const float* dir, const float* u,
+                           int32_t* prim, float* ld);
+
 /* The two direction bytes a photon is stored with, for n world-space
  * directions wo (src/tracer/TkSppmTracer.cpp:135-140, :193-198).  Host arrays. */
 int tkhip_encode_directions(tkhip_ctx* ctx, int64_t n, const float* wo, uint8_t* theta, uint8_t* phi);

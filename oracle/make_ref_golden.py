@@ -35,6 +35,7 @@ GROUPS = {
     "ref_rays_sphere.npz": ["rays_sphere_"],
     "ref_rays_dragon.npz": ["rays_dragon_"],
     "ref_trace_tile.npz": ["tile_"],
+    "ref_nee.npz": ["nee_"],   # inputs: the first rays of the ref_rays_* fixtures of the same scene
 }
 
 

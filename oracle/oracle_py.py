@@ -44,6 +44,7 @@ def lib():
                                           C.POINTER(_abi.TkLight), C.c_int]),
         "orc_scene_destroy": (None, [C.c_void_p]),
         "orc_scene_set_camera": (None, [C.c_void_p, f32p, f32p, C.c_int, C.c_int]),
+        "orc_sample_one_light": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p, i32p, f32p, C.c_int]),
         "orc_trace_rays": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p, i32p, f32p, f32p, f32p, f32p, C.c_int]),
         "orc_camera_rays": (None, [C.c_void_p, C.c_int64, f32p, f32p, f32p]),
         "orc_sample_f": (None, [C.POINTER(_abi.TkMaterial), C.c_int, C.c_int64, f32p, f32p, f32p, f32p, f32p, f32p]),
@@ -132,6 +133,14 @@ class OracleScene:
         lib().orc_trace_rays(self.h, n, fp(org), fp(direction), fp(tm), ip(prim), fp(t), fp(p), fp(nrm), fp(perr),
                              faithful)
         return prim, t, p, nrm, perr
+
+    def sample_one_light(self, org, direction, u, faithful=0):
+        org, direction, u = f32(org), f32(direction), f32(u)
+        n = org.shape[0]
+        prim = np.empty(n, np.int32)
+        ld = np.empty((n, 3), np.float32)
+        lib().orc_sample_one_light(self.h, n, fp(org), fp(direction), fp(u), ip(prim), fp(ld), faithful)
+        return prim, ld
 
     def camera_rays(self, raster):
         raster = f32(raster)

@@ -342,6 +342,17 @@ static void probe_photon_map() {
     }
 }
 
+// A sampler that hands out four given numbers: what Scene::uniformSampleOneLight draws, in its order
+// (get1D: the light, get2D: the point on it, get1D: the triangle of its mesh).
+struct FixedSampler : public Sampler {
+    float v[4];
+    int at;
+    FixedSampler() : Sampler(1), at(0) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+    float get1D() override { return v[at++ & 3]; }
+    Vector2f get2D() override { float a = v[at++ & 3], b = v[at++ & 3]; return Vector2f(a, b); }
+    std::unique_ptr<Sampler> clone(int) override { return std::unique_ptr<Sampler>(); }
+};
+
 // ------------------------------------------------------------------- rays
 static Config* load(const char* file) {
     Config* cfg = new Config();
@@ -357,6 +368,10 @@ static void probe_rays(const char* file, const std::string& tag, int n_rays, uin
     std::vector<float> org, dir, t, p, nrm, perr, wo;
     std::vector<int32_t> hit, objidx;
     const ObjectPtrVec& objs = sc->get_objects();
+    // Scene::uniformSampleOneLight at the hits of the first rays
+    const int n_nee = n_rays < 8192 ? n_rays : 8192;
+    std::vector<float> nee_u, nee_ld;
+    Rng r4(seed + 3);
     Vector3f cur_o(0, 0, -6.5f);
     for (int i = 0; i < n_rays; ++i) {
         Vector3f o, d;
@@ -383,6 +398,12 @@ static void probe_rays(const char* file, const std::string& tag, int n_rays, uin
         bool h = sc->intersect(ray, &is);
         push3(org, o); push3(dir, d);
         hit.push_back(h ? 1 : 0);
+        if (i < n_nee) {
+            FixedSampler fs;
+            for (int c = 0; c < 4; ++c) { fs.v[c] = r4.u(); nee_u.push_back(fs.v[c]); }
+            Spectrum L = h ? sc->uniformSampleOneLight(is, fs) : Spectrum(0.f, 0.f, 0.f);
+            pushs(nee_ld, L);
+        }
         if (h) {
             t.push_back((float)ray.t_max);
             push3(p, is.p); push3(nrm, is.n); push3(perr, is.pError); push3(wo, is.wo);
@@ -400,6 +421,9 @@ static void probe_rays(const char* file, const std::string& tag, int n_rays, uin
     save(tag + "_org", org, {n, 3}); save(tag + "_dir", dir, {n, 3}); save(tag + "_hit", hit, {n});
     save(tag + "_t", t, {n}); save(tag + "_p", p, {n, 3}); save(tag + "_n", nrm, {n, 3});
     save(tag + "_perr", perr, {n, 3}); save(tag + "_wo", wo, {n, 3}); save(tag + "_obj", objidx, {n});
+    // "rays_<scene>" -> "nee_<scene>": the light samples go into a fixture of their own
+    const std::string ntag = "nee_" + tag.substr(5);
+    save(ntag + "_u", nee_u, {(size_t)n_nee, 4}); save(ntag + "_ld", nee_ld, {(size_t)n_nee, 3});
 
     // Intersection::spawnRay / spawnRayTo on the hits just found (offsetRayOrigin)
     std::vector<float> sp_in, sp_out;

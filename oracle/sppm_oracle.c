@@ -1634,26 +1634,44 @@ void orc_sppm_build_maps(orc_sppm* r, TkIterStats* st) {
 /* ----------------------------------------------------------- camera pass */
 typedef struct { int64_t rays, gg, gc, gphot; TraceCounters tc; float* d2; int32_t* nb; } CamThread;
 
-/* Scene::uniformSampleOneLight, src/core/Scene.cpp:43-61 */
-static v3 uniform_sample_one_light(const orc_sppm* r, const Isect* it, Sampler* sm, TraceCounters* tc) {
-    const orc_scene* s = r->sc;
+/* Scene::uniformSampleOneLight, src/core/Scene.cpp:43-61, with the four numbers it takes from the
+ * sampler given: which light, the point on it (2), which triangle of its mesh. */
+static v3 one_light_with(const orc_scene* s, int faithful, const Isect* it, float u_choice, float ulx, float uly,
+                         float u0, TraceCounters* tc) {
     int nl = s->n_lights;
-    if (nl == 0) return V(0, 0, 0);
-    int idx = (int)(sampler_get1d(sm) * nl);
+    int idx = (int)(u_choice * nl);
     if (idx > nl - 1) idx = nl - 1;
     float pdf_choice = 1.0f / nl;
-    float ulx, uly;
-    sampler_get2d(sm, &ulx, &uly);
     v3 ws = V(0, 0, 0); float pdf_light = 0; Isect li; memset(&li, 0, sizeof(li));
-    float u0 = sampler_get1d(sm);
     v3 Li = light_sample_li(s, idx, it, u0, ulx, uly, &li, &ws, &pdf_light);
     if (Li.x == 0 && Li.y == 0 && Li.z == 0) return V(0, 0, 0);
     Ray sr = spawn_ray_to(it, &li);
     Isect tmp; memset(&tmp, 0, sizeof(tmp));
-    if (scene_intersect(s, &sr, &tmp, r->faithful, tc)) return V(0, 0, 0);
+    if (scene_intersect(s, &sr, &tmp, faithful, tc)) return V(0, 0, 0);
     const TkMaterial* m = &s->mats[s->objects[it->obj].material];
     v3 f = mat_f(m, it->wo, ws, it->n);
     return vdivs(vscale(vmul(Li, f), vabsdot(ws, it->n)), pdf_light * pdf_choice);
+}
+static v3 uniform_sample_one_light(const orc_sppm* r, const Isect* it, Sampler* sm, TraceCounters* tc) {
+    const orc_scene* s = r->sc;
+    if (s->n_lights == 0) return V(0, 0, 0);
+    float uc = sampler_get1d(sm);
+    float ulx, uly;
+    sampler_get2d(sm, &ulx, &uly);
+    float u0 = sampler_get1d(sm);
+    return one_light_with(s, r->faithful, it, uc, ulx, uly, u0, tc);
+}
+void orc_sample_one_light(orc_scene* s, int64_t n, const float* org, const float* dir, const float* u, int32_t* prim,
+                          float* ld, int faithful) {
+    for (int64_t i = 0; i < n; ++i) {
+        Ray r = make_ray(ld3(org + 3 * i), ld3(dir + 3 * i));
+        Isect is; memset(&is, 0, sizeof(is)); is.prim = -1;
+        int h = scene_intersect(s, &r, &is, faithful, 0);
+        prim[i] = h ? is.prim : -1;
+        v3 L = V(0, 0, 0);
+        if (h && s->n_lights > 0) L = one_light_with(s, faithful, &is, u[4 * i], u[4 * i + 1], u[4 * i + 2], u[4 * i + 3], 0);
+        st3(ld + 3 * i, L);
+    }
 }
 
 /* One pixel of traceTile, src/tracer/TkSppmTracer.cpp:296-371.  With

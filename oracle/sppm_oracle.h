@@ -56,6 +56,10 @@ void orc_scene_set_camera(orc_scene* s, const float c2w[16], const float raster2
 void orc_trace_rays(orc_scene* s, int64_t n, const float* org, const float* dir,
                     const float* tmax, int32_t* prim, float* t, float* p, float* nrm,
                     float* perr, int faithful);
+/* Scene::uniformSampleOneLight (src/core/Scene.cpp:43-61) at the first hit of each ray; u: per ray
+ * the four numbers the call takes from its sampler (light, point on it x2, triangle of its mesh). */
+void orc_sample_one_light(orc_scene* s, int64_t n, const float* org, const float* dir, const float* u,
+                          int32_t* prim, float* ld, int faithful);
 void orc_camera_rays(orc_scene* s, int64_t n, const float* raster, float* org, float* dir);
 /* Material::sample_f for n samples: mode 0 Radiance, 1 Importance. */
 void orc_sample_f(const TkMaterial* m, int mode, int64_t n, const float* wo, const float* nrm,

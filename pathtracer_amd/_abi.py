@@ -161,6 +161,7 @@ TKHIP_SYMBOLS = {
                                            C.c_int, c_uint8_p, C.c_int, C.c_uint64, c_float_p]),
     "tkhip_spawn_rays": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_float_p, c_float_p, c_float_p]),
+    "tkhip_sample_one_light": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_int32_p, c_float_p]),
     "tkhip_encode_directions": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_uint8_p, c_uint8_p]),
     "tkhip_sppm_read_photons": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_uint8_p, c_uint8_p,
                                           c_int64_p]),

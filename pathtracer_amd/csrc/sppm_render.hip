@@ -650,36 +650,15 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
     F3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 0), ld_light = mk3(0, 0, 0);
     if ((pt || has_glossy || !diffuse) && sc.n_lights > 0) {
         // uniformSampleOneLight: the sampler dimensions advance for every material
-        int nl = sc.n_lights;
-        int li = (int)(sampler_get1d(sm) * nl);
-        li = li > nl - 1 ? nl - 1 : li;
-        float pdf_choice = 1.0f / nl;
+        const float uc = sampler_get1d(sm);
         float ulx, uly;
         sampler_get2d(sm, &ulx, &uly);
-        float u0 = sampler_get1d(sm);
-        if (diffuse) {   // f() of mirror and glass is black: nothing to add, no shadow ray needed
-            const DLight L = sc.lights[li];
-            float pd, tmp;
-            int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, u0, &pd);
-            LightPoint lp = tri_sample(sc, L.tri_first + idx, ulx, uly, &tmp);
-            F3 wv = sub3(lp.p, sp.p);
-            float dist2 = dot3(wv, wv);
-            if (dist2 == 0) tmp = 0;
-            else { F3 wn = normalize3(wv); tmp *= dist2 / absdot3(lp.n, neg3(wn)); }
-            float pdf_light = pd * tmp;
-            if (!(pdf_light == 0 || dist2 == 0)) {
-                F3 ws = normalize3(wv);
-                F3 Li = light_L(L, lp.n, neg3(ws));
-                if (!isblack(Li)) {
-                    // Intersection::spawnRayTo(other), src/Intersection.hpp:40-48
-                    sh_o = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
-                    F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(sh_o, lp.p));
-                    sh_d = sub3(target, sh_o);
-                    F3 f = mat_f(m, sp.wo, ws, sp.n);
-                    ld_light = mul3(coef, divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice));
-                    want_shadow = true;
-                }
-            }
+        const float u0 = sampler_get1d(sm);
+        const LightSample ls = sample_one_light(sc, sp, m, uc, ulx, uly, u0);
+        if (ls.want_shadow) {
+            sh_o = ls.o; sh_d = ls.d;
+            ld_light = mul3(coef, ls.ld);
+            want_shadow = true;
         }
     }
     // what follows the light sample does not depend on the shadow ray's answer

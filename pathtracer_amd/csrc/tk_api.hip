@@ -56,6 +56,29 @@ __global__ void __launch_bounds__(256) k_trace_rays(DScene sc, int64_t n, const 
     if (perr) { perr[3 * i] = sp.perr.x; perr[3 * i + 1] = sp.perr.y; perr[3 * i + 2] = sp.perr.z; }
 }
 
+// Scene::uniformSampleOneLight (src/core/Scene.cpp:43-61) at the first hit of each ray, with the four
+// numbers the sampler would deliver given by the caller: the hit, the light sample, its shadow ray.
+__global__ void __launch_bounds__(256) k_sample_one_light(DScene sc, int64_t n, const float* org, const float* dir,
+                                                          const float* u, int32_t* prim, float* ld) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
+    const Hit h = trace_ray(sc, o, d, 1.7976931348623157e308, false, stk);
+    prim[i] = h.prim;
+    F3 out = mk3(0, 0, 0);
+    if (h.prim >= 0) {
+        const SurfacePoint sp = surface_at(sc, h, o, d);
+        const LightSample ls = sample_one_light(sc, sp, sc.mats[sp.mat], u[4 * i], u[4 * i + 1], u[4 * i + 2], u[4 * i + 3]);
+        if (ls.want_shadow) {
+            const Hit sh = trace_ray(sc, ls.o, ls.d, (double)kOneMinusEps, true, stk);
+            if (sh.prim < 0) out = ls.ld;
+        }
+    }
+    ld[3 * i] = out.x; ld[3 * i + 1] = out.y; ld[3 * i + 2] = out.z;
+}
+
 __global__ void k_radical_inverse(int64_t n, const int32_t* dim, const uint64_t* index, float* out) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = radical_inverse(dim[i], index[i]);
@@ -584,6 +607,33 @@ int tkhip_trace_rays(tkhip_ctx* ctx, int64_t n, const float* org, const float* d
     in.release();
     out.release();
     if (e != hipSuccess) { set_error("tkhip_trace_rays: %s", hipGetErrorString(e)); return TKHIP_E_HIP; }
+    return TKHIP_OK;
+}
+
+int tkhip_sample_one_light(tkhip_ctx* ctx, int64_t n, const float* org, const float* dir, const float* u, int32_t* prim,
+                           float* ld) {
+    TK_REQUIRE(ctx && (n == 0 || (org && dir && u && prim && ld)), TKHIP_E_ARG, "tkhip_sample_one_light: null argument");
+    TK_REQUIRE(ctx->has_scene, TKHIP_E_STATE, "tkhip_sample_one_light: no scene set");
+    TK_REQUIRE(n >= 0 && n < (int64_t)1 << 28, TKHIP_E_LIMIT, "tkhip_sample_one_light: ray count out of range");
+    if (n == 0) return TKHIP_OK;
+    TK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t q = (size_t)n;
+    TK_TRY(ctx->scratch_a.ensure(q * 40));
+    TK_TRY(ctx->scratch_b.ensure(q * 16));
+    float* dorg = ctx->scratch_a.as<float>();
+    float* ddir = dorg + 3 * q;
+    float* du = ddir + 3 * q;
+    int32_t* dprim = ctx->scratch_b.as<int32_t>();
+    float* dld = ctx->scratch_b.as<float>() + q;
+    TK_HIP(hipMemcpyAsync(dorg, org, q * 12, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(ddir, dir, q * 12, hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(du, u, q * 16, hipMemcpyHostToDevice, s));
+    k_sample_one_light<<<divup(n, kTraceBlock), kTraceBlock, 0, s>>>(ctx->scene, n, dorg, ddir, du, dprim, dld);
+    TK_LAUNCH_CHECK();
+    TK_HIP(hipMemcpyAsync(prim, dprim, q * 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipMemcpyAsync(ld, dld, q * 12, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
     return TKHIP_OK;
 }
 

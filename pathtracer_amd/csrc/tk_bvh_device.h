@@ -377,6 +377,47 @@ TKD F3 light_L(const DLight& l, F3 n, F3 w) {                  // src/Light.cpp:
     return (l.two_sided || dot3(n, w) > 0) ? ld3(l.Le) : mk3(0, 0, 0);
 }
 
+// Scene::uniformSampleOneLight (src/core/Scene.cpp:43-61) up to its shadow ray.  The light is picked by
+// u_choice, the triangle of its mesh by u_tri and the point on it by (ulx, uly) (AreaLight::sample_Li,
+// src/Light.cpp:24-39); the shadow ray is Intersection::spawnRayTo(other) (src/Intersection.hpp:40-48);
+// `ld` is what the sample adds when that ray reaches the light.  f() of mirror and glass is black: a
+// surface that is not diffuse gets no sample (and needs no shadow ray).
+struct LightSample {
+    bool want_shadow;
+    F3 o, d, ld;
+};
+TKD LightSample sample_one_light(const DScene& sc, const SurfacePoint& sp, const TkMaterial& m, float u_choice, float ulx,
+                                 float uly, float u_tri) {
+    LightSample r;
+    r.want_shadow = false;
+    r.o = r.d = r.ld = mk3(0, 0, 0);
+    const int nl = sc.n_lights;
+    if (nl <= 0 || m.type != TK_DIFFUSE) return r;
+    int li = (int)(u_choice * nl);
+    li = li > nl - 1 ? nl - 1 : li;
+    const float pdf_choice = 1.0f / nl;
+    const DLight L = sc.lights[li];
+    float pd, tmp;
+    const int idx = sample_discrete(sc.light_cdf + L.cdf_first, L.tri_count, u_tri, &pd);
+    const LightPoint lp = tri_sample(sc, L.tri_first + idx, ulx, uly, &tmp);
+    const F3 wv = sub3(lp.p, sp.p);
+    const float dist2 = dot3(wv, wv);
+    if (dist2 == 0) tmp = 0;
+    else { const F3 wn = normalize3(wv); tmp *= dist2 / absdot3(lp.n, neg3(wn)); }
+    const float pdf_light = pd * tmp;
+    if (pdf_light == 0 || dist2 == 0) return r;
+    const F3 ws = normalize3(wv);
+    const F3 Li = light_L(L, lp.n, neg3(ws));
+    if (isblack(Li)) return r;
+    r.o = offset_ray_origin(sp.p, sp.perr, sp.n, sub3(lp.p, sp.p));
+    const F3 target = offset_ray_origin(lp.p, lp.perr, lp.n, sub3(r.o, lp.p));
+    r.d = sub3(target, r.o);
+    const F3 f = mat_f(m, sp.wo, ws, sp.n);
+    r.ld = divs3(scale3(mul3(Li, f), absdot3(ws, sp.n)), pdf_light * pdf_choice);
+    r.want_shadow = true;
+    return r;
+}
+
 // AreaLight::sample_Le (src/Light.cpp:41-75) with MeshTriangle::Sample's
 // triangle pick drawn from `upick` (src/Triangle.cpp:190-197): a point on the
 // light, a cosine-distributed direction about its normal, the spawned ray.

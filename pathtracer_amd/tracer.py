@@ -145,6 +145,16 @@ class Context:
               "tkhip_spawn_rays")
         return tuple(outs)
 
+    def sample_one_light(self, org, direction, u):
+        """Scene::uniformSampleOneLight at the first hit of each ray; u: the four sampler numbers per ray."""
+        org, direction, u = _f32(org), _f32(direction), _f32(u)
+        n = org.shape[0]
+        prim = np.empty(n, np.int32)
+        ld = np.empty((n, 3), np.float32)
+        check(self.lib, self.lib.tkhip_sample_one_light(self.h, n, _fp(org), _fp(direction), _fp(u), _ip(prim), _fp(ld)),
+              "tkhip_sample_one_light")
+        return prim, ld
+
     def encode_directions(self, wo):
         wo = _f32(wo)
         n = wo.shape[0]

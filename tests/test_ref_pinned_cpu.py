@@ -178,6 +178,26 @@ def test_sample_le_matches_upstream(name):
     assert matched.all(), int((~matched).sum())
 
 
+@pytest.mark.parametrize("name", ["box", "sphere", "dragon"])
+def test_one_light_sample_matches_upstream(name):
+    """Scene::uniformSampleOneLight at the hits of the first rays of the ray fixture, with the four
+    numbers it takes from its sampler given: light pick, AreaLight::sample_Li, the shadow ray of
+    spawnRayTo, intersectP, Material::f.  The returned spectrum bit for bit (no libm call on the way)."""
+    g, r = golden("ref_nee.npz"), golden(f"ref_rays_{name}.npz")
+    u, want = g[f"nee_{name}_u"], g[f"nee_{name}_ld"]
+    n = len(u)
+    sc = Scene.load(asset_scene(f"cornell_{name}.scene"))
+    osc = O.OracleScene(sc, 64, 64)
+    for faithful in (0, 1):
+        m = n if not (name == "dragon" and faithful) else 2000
+        prim, ld = osc.sample_one_light(r[f"rays_{name}_org"][:m], r[f"rays_{name}_dir"][:m], u[:m], faithful=faithful)
+        assert ((prim >= 0) == (r[f"rays_{name}_hit"][:m] == 1)).all()
+        assert bits_equal(ld, want[:m])
+    osc.close()
+    lit = (want != 0).any(axis=1)
+    assert 0.2 < lit.mean() < 0.6      # neither all shadowed nor all lit: both outcomes are in the fixture
+
+
 def test_trace_tile_matches_upstream():
     """SppmTracer::traceTile on given photon maps with an unjittered sampler, two iterations: camera
     paths, next-event estimation, both radiance estimates and the SPPMPixel update.  Ld, photon

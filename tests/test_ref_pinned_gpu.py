@@ -116,6 +116,20 @@ def test_ray_hits_match_upstream(gpu_ctx, name):
     assert matched.all(), int((~matched).sum())
 
 
+@pytest.mark.parametrize("name", ["box", "sphere", "dragon"])
+def test_one_light_sample_matches_upstream(gpu_ctx, name):
+    """Scene::uniformSampleOneLight of upstream at the hits of the first rays of the ray fixture, with the
+    four sampler numbers given: light pick, point on the light, shadow ray, occlusion test, f().  The
+    spectrum bit for bit, through the function the camera path kernels call."""
+    g, r = golden("ref_nee.npz"), golden(f"ref_rays_{name}.npz")
+    u, want = g[f"nee_{name}_u"], g[f"nee_{name}_ld"]
+    n = len(u)
+    gpu_ctx.set_scene(Scene.load(asset_scene(f"cornell_{name}.scene")))
+    prim, ld = gpu_ctx.sample_one_light(r[f"rays_{name}_org"][:n], r[f"rays_{name}_dir"][:n], u)
+    assert ((prim >= 0) == (r[f"rays_{name}_hit"][:n] == 1)).all()
+    assert bits_equal(ld, want)
+
+
 @pytest.mark.parametrize("tag", list(MATERIALS))
 @pytest.mark.parametrize("mode", [0, 1])
 def test_sample_f_matches_upstream(gpu_ctx, tag, mode):
