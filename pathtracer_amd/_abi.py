@@ -162,6 +162,7 @@ TKHIP_SYMBOLS = {
     "tkhip_spawn_rays": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_float_p, c_float_p, c_float_p]),
     "tkhip_sample_one_light": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_int32_p, c_float_p]),
+    "tkhip_set_wide_walk": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_encode_directions": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_uint8_p, c_uint8_p]),
     "tkhip_sppm_read_photons": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_uint8_p, c_uint8_p,
                                           c_int64_p]),

@@ -272,4 +272,62 @@ void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int 
     lap("nodes laid out");
 }
 
+// Wide nodes, breadth first: a node's children start as the two of its two-children node; the inner child
+// with the largest surface is replaced by its own two until there are eight or none is inner.
+int collapse_bvh(const BvhNode* nodes, int n_nodes, std::vector<WideNode>* out) {
+    out->clear();
+    if (n_nodes <= 0) return 0;
+    struct Item { int node, wide, depth; };
+    std::vector<Item> todo;
+    todo.reserve((size_t)n_nodes / 2 + 1);
+    out->reserve((size_t)n_nodes / 2 + 1);
+    out->emplace_back();
+    todo.push_back({0, 0, 1});
+    int max_depth = 1;
+    auto area = [](const WideChild& c) {
+        const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto children_of = [&](int node, WideChild* l, WideChild* r) {
+        const BvhNode& nd = nodes[node];
+        for (int a = 0; a < 3; ++a) { l->lo[a] = nd.lmin[a]; l->hi[a] = nd.lmax[a]; r->lo[a] = nd.rmin[a]; r->hi[a] = nd.rmax[a]; }
+        l->ref = nd.left; r->ref = nd.right;
+        l->pad = r->pad = 0;
+    };
+    for (size_t at = 0; at < todo.size(); ++at) {
+        const Item it = todo[at];
+        max_depth = std::max(max_depth, it.depth);
+        WideChild ch[8];
+        int n = 2;
+        children_of(it.node, &ch[0], &ch[1]);
+        while (n < 8) {
+            int pick = -1;
+            float best = -1.f;
+            for (int i = 0; i < n; ++i)
+                if (ch[i].ref >= 0 && area(ch[i]) > best) { best = area(ch[i]); pick = i; }
+            if (pick < 0) break;
+            const int node = ch[pick].ref;
+            children_of(node, &ch[pick], &ch[n]);
+            ++n;
+        }
+        WideNode w;
+        for (int i = 0; i < 8; ++i) {
+            if (i < n) {
+                w.c[i] = ch[i];
+                if (ch[i].ref >= 0) {
+                    w.c[i].ref = (int32_t)out->size();
+                    out->emplace_back();
+                    todo.push_back({ch[i].ref, w.c[i].ref, it.depth + 1});
+                }
+            } else {
+                for (int a = 0; a < 3; ++a) { w.c[i].lo[a] = INFINITY; w.c[i].hi[a] = -INFINITY; }
+                w.c[i].ref = kWideEmpty;
+                w.c[i].pad = 0;
+            }
+        }
+        (*out)[(size_t)it.wide] = w;
+    }
+    return max_depth;
+}
+
 }  // namespace tkd

@@ -1903,12 +1903,13 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     // the groups with many lanes at k or above (their number is known to the device only: the waves of a
     // grid that fills the GPU once share them out)
     const int sel_blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), select_grid_blocks(m->ctx->device));
-    if (!sc.heavy) {}
-    else if (out.idx)
-        k_gather_select<true><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
-    else
-        k_gather_select<false><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
-    TK_LAUNCH_CHECK();
+    if (sc.heavy) {
+        if (out.idx)
+            k_gather_select<true><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+        else
+            k_gather_select<false><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+        TK_LAUNCH_CHECK();
+    }
     m->ev_pending = true;
     m->group_queries += nq;
     if (timed) {

@@ -475,16 +475,30 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
             if (exhausted) break;
             continue;
         }
-        if (alive && !in_flight) {
+        const int n_alive = __popcll(__ballot(alive));
+        const bool last = exhausted && a.sc.wide && n_alive <= a.sc.wide_rays;
+        if (last && !__any(in_flight)) break;   // the last paths: below
+        if (alive && !in_flight && !last) {
             walk_begin(w, a.sc, P.d, 1.7976931348623157e308);
             in_flight = true;
             ++traced;
         }
-        walk_rays(a.sc, w, P.o, P.d, false, stk, __popcll(__ballot(alive)) >> kWalkRestShift);
-        if (alive && w.cur == kWalkOver) {   // this lane's ray has finished: the bounce, then its next ray
+        walk_rays(a.sc, w, P.o, P.d, false, stk, last ? 0 : n_alive >> kWalkRestShift);   // last: the rays under way are finished, none begun
+        if (alive && in_flight && w.cur == kWalkOver) {   // this lane's ray has finished: the bounce, then its next ray
             bool specular;
             alive = photon_on_hit<KIND>(a, slot, bounce, P, w.h, &specular);
             in_flight = false;
+            ++bounce;
+            if (KIND == 0 && !alive) a.rec_count[slot] = P.flags;
+        }
+    }
+    // the few paths left once the queue is empty: eight lanes to a ray in the wide tree (see k_camera_paths)
+    while (__any(alive)) {
+        const Hit h = walk_wide(a.sc, alive, P.o, P.d, 1.7976931348623157e308, false, stk);
+        if (alive) {
+            ++traced;
+            bool specular;
+            alive = photon_on_hit<KIND>(a, slot, bounce, P, h, &specular);
             ++bounce;
             if (KIND == 0 && !alive) a.rec_count[slot] = P.flags;
         }
@@ -806,19 +820,34 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
             if (exhausted) break;
             continue;
         }
-        if (alive && !in_flight) {
+        const int n_alive = __popcll(__ballot(alive));
+        const bool last = exhausted && a.sc.wide && n_alive <= a.sc.wide_rays;
+        if (last && !__any(in_flight)) break;   // the last paths: below
+        if (alive && !in_flight && !last) {
             walk_begin(w, a.sc, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308);
             in_flight = true;
             ++nrays;
         }
-        walk_rays(a.sc, w, P.o, P.d, P.shadow, stk, __popcll(__ballot(alive)) >> kWalkRestShift);
+        walk_rays(a.sc, w, P.o, P.d, P.shadow, stk, last ? 0 : n_alive >> kWalkRestShift);   // last: the rays under way are finished, none begun
         CameraStepOut so{};
         so.want_cq = so.want_gq = false;
-        if (alive && w.cur == kWalkOver) {   // this lane's ray has finished: what follows from it, then its next ray
+        if (alive && in_flight && w.cur == kWalkOver) {   // this lane's ray has finished: what follows from it, then its next ray
             alive = camera_after_ray(a, x, y, pixel, bounce, P, so, w.h);
             in_flight = false;
         }
         camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
+    }
+    // The few paths a wave is left with once the queue is empty (none with a ray under way): eight lanes to
+    // a ray in the wide tree.  A loop of its own, so that the loop above keeps its registers.
+    while (__any(alive)) {
+        const Hit h = walk_wide(a.sc, alive, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+        CameraStepOut so{};
+        so.want_cq = so.want_gq = false;
+        if (alive) {
+            ++nrays;
+            alive = camera_after_ray(a, x, y, pixel, bounce, P, so, h);
+        }
+        camera_emit_queries(a, counters, so, pixel);
     }
     count_wave_rays(counters, nrays);
 }

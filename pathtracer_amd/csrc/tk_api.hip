@@ -56,6 +56,28 @@ __global__ void __launch_bounds__(256) k_trace_rays(DScene sc, int64_t n, const 
     if (perr) { perr[3 * i] = sp.perr.x; perr[3 * i + 1] = sp.perr.y; perr[3 * i + 2] = sp.perr.z; }
 }
 
+// The same through the wide walk (eight lanes per ray, eight rays of a wave at a time).
+__global__ void __launch_bounds__(256) k_trace_rays_wide(DScene sc, int64_t n, const float* org, const float* dir,
+                                                         const float* tmax, int32_t* prim, float* t, float* p, float* nrm,
+                                                         float* perr) {
+    __shared__ int s_stack[kStackDepth * kTraceBlock];
+    LdsStack stk{&s_stack[threadIdx.x]};
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool want = i < n;
+    F3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+    double tm = 1.7976931348623157e308;
+    if (want) { o = ld3(org + 3 * i); d = ld3(dir + 3 * i); if (tmax) tm = (double)tmax[i]; }
+    Hit h = walk_wide(sc, want, o, d, tm, false, stk);
+    if (!want) return;
+    prim[i] = h.prim;
+    SurfacePoint sp{};
+    if (h.prim >= 0) sp = surface_at(sc, h, o, d);
+    if (t) t[i] = h.prim >= 0 ? (float)h.t : 0.f;
+    if (p) { p[3 * i] = sp.p.x; p[3 * i + 1] = sp.p.y; p[3 * i + 2] = sp.p.z; }
+    if (nrm) { nrm[3 * i] = sp.n.x; nrm[3 * i + 1] = sp.n.y; nrm[3 * i + 2] = sp.n.z; }
+    if (perr) { perr[3 * i] = sp.perr.x; perr[3 * i + 1] = sp.perr.y; perr[3 * i + 2] = sp.perr.z; }
+}
+
 // Scene::uniformSampleOneLight (src/core/Scene.cpp:43-61) at the first hit of each ray, with the four
 // numbers the sampler would deliver given by the caller: the hit, the light sample, its shadow ray.
 __global__ void __launch_bounds__(256) k_sample_one_light(DScene sc, int64_t n, const float* org, const float* dir,
@@ -118,6 +140,7 @@ int tkhip_create(int device, tkhip_ctx** out) {
     TK_HIP(hipSetDevice(device));
     tkhip_ctx* ctx = new tkhip_ctx();
     ctx->device = device;
+    if (const char* e = getenv("TKHIP_WIDE_RAYS")) ctx->wide_rays = std::min(std::max(atoi(e), 0), 64);   // tuning aid
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("tkhip_create: hipStreamCreate: %s", hipGetErrorString(e));
@@ -145,7 +168,7 @@ void tkhip_destroy(tkhip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     destroy_sppm(ctx);
-    DevBuf* bufs[] = {&ctx->b_nodes, &ctx->b_tri_isect, &ctx->b_tri_shade, &ctx->b_spheres, &ctx->b_prim_mat,
+    DevBuf* bufs[] = {&ctx->b_wide, &ctx->b_nodes, &ctx->b_tri_isect, &ctx->b_tri_shade, &ctx->b_spheres, &ctx->b_prim_mat,
                       &ctx->b_mats, &ctx->b_lights, &ctx->b_cdf, &ctx->b_dirtab, &ctx->scratch_a, &ctx->scratch_b,
                       &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->scratch_f, &ctx->prim_temp};
     for (DevBuf* b : bufs) b->release();
@@ -157,6 +180,14 @@ int tkhip_set_bvh_builder(tkhip_ctx* ctx, int mode) {
     TK_REQUIRE(ctx, TKHIP_E_ARG, "tkhip_set_bvh_builder: null context");
     TK_REQUIRE(mode >= 0 && mode <= 2, TKHIP_E_ARG, "tkhip_set_bvh_builder: mode %d (0 by size, 1 host, 2 device)", mode);
     ctx->bvh_builder = mode;
+    return TKHIP_OK;
+}
+
+int tkhip_set_wide_walk(tkhip_ctx* ctx, int max_rays) {
+    TK_REQUIRE(ctx, TKHIP_E_ARG, "tkhip_set_wide_walk: null context");
+    TK_REQUIRE(max_rays >= 0 && max_rays <= 64, TKHIP_E_ARG, "tkhip_set_wide_walk: %d outside 0..64", max_rays);
+    ctx->wide_rays = max_rays;
+    ctx->scene.wide_rays = max_rays;
     return TKHIP_OK;
 }
 
@@ -256,6 +287,23 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
         depth = bvh.max_depth;
         for (int a = 0; a < 3; ++a) { bmin[a] = bvh.bmin[a]; bmax[a] = bvh.bmax[a]; }
     }
+    // the eight-children form of the tree for the wide walk: every ray stack must fit its LDS columns
+    ctx->wide_depth = 0;
+    bool have_wide = false;
+    if (n_nodes > 0 && n_nodes <= kWideMaxNodes) {
+        std::vector<BvhNode> host_nodes((size_t)n_nodes);
+        TK_HIP(hipMemcpyAsync(host_nodes.data(), ctx->b_nodes.p, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost, s));
+        TK_HIP(hipStreamSynchronize(s));
+        std::vector<WideNode> wide;
+        const int wd = collapse_bvh(host_nodes.data(), n_nodes, &wide);
+        if (wd * 7 <= kWideStack) {
+            TK_TRY(upload(ctx->b_wide, wide, s));
+            TK_HIP(hipStreamSynchronize(s));
+            ctx->wide_depth = wd;
+            have_wide = true;
+        }
+        lap("wide nodes");
+    }
     ctx->bvh_on_device = on_device ? 1 : 0;
     ctx->bvh_depth = depth;
     ctx->bvh_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
@@ -331,6 +379,8 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
     sc.light_cdf = ctx->b_cdf.as<float>();
     sc.n_tris = n_tris; sc.n_spheres = n_spheres; sc.n_lights = n_lights;
     sc.n_nodes = n_nodes;
+    sc.wide = have_wide ? ctx->b_wide.as<WideNode>() : nullptr;
+    sc.wide_rays = ctx->wide_rays;
     for (int a = 0; a < 3; ++a) { sc.bmin[a] = bmin[a]; sc.bmax[a] = bmax[a]; }
     // bounds of the specular objects, padded by a ten-thousandth of the scene's extent
     sc.n_spec_boxes = 0;
@@ -594,8 +644,12 @@ int tkhip_trace_rays(tkhip_ctx* ctx, int64_t n, const float* org, const float* d
     if (e == hipSuccess) e = hipMemcpyAsync(ddir, dir, q * 12, hipMemcpyHostToDevice, s);
     if (e == hipSuccess && tmax) e = hipMemcpyAsync(dtm, tmax, q * 4, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        k_trace_rays<<<divup(n, kTraceBlock), kTraceBlock, 0, s>>>(ctx->scene, n, dorg, ddir, tmax ? dtm : nullptr, dprim, dt,
-                                                                 dp, dn, de);
+        if (ctx->scene.wide && ctx->scene.wide_rays >= 64)
+            k_trace_rays_wide<<<divup(n, kTraceBlock), kTraceBlock, 0, s>>>(ctx->scene, n, dorg, ddir, tmax ? dtm : nullptr, dprim,
+                                                                          dt, dp, dn, de);
+        else
+            k_trace_rays<<<divup(n, kTraceBlock), kTraceBlock, 0, s>>>(ctx->scene, n, dorg, ddir, tmax ? dtm : nullptr, dprim, dt,
+                                                                     dp, dn, de);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -306,6 +306,114 @@ TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK
     return w.h;
 }
 
+// ---------------------------------------------------------------- wide walk
+// Closest hit (or occlusion) for up to a few rays of a wave, eight lanes per ray, in the tree of wide
+// nodes: the eight lanes of a group test the eight child boxes of a node side by side, the leaves among
+// the children that are hit are tested at once (each by the lane that holds it), the nearest inner child
+// is visited next and the others go on the ray's stack with their entry distances.  A ray takes a third
+// of the dependent round trips of the one-lane walk above, which is what a wave with few rays left waits
+// for.  The boxes and the primitive tests are the same as in walk_rays and a box that holds a hit is never
+// culled in either, so the hit is the same (up to the order in which primitives at exactly the same
+// distance are met).
+//
+// Called by all 64 lanes; `want` marks the lanes with a ray (any number: eight are served at a time).
+// The per-lane LDS stacks must be free (no one-lane walk in flight): a group keeps its stack in the
+// eight columns of its lanes, references in the upper half of the rows, distances in the lower.
+constexpr int kWideStack = kStackDepth / 2 * 8;   // entries a ray can hold
+TKD uint32_t wide_order_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+template <int STRIDE>
+TKD Hit walk_wide(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_in, bool any_hit_in, LdsStackT<STRIDE> st) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int sub = lane & 7, grp = lane >> 3, lane0 = grp << 3;
+    int* const col = st.base - lane + lane0;         // row 0 of the group's first column
+    Hit result;
+    result.prim = -1; result.t = tmax_in; result.u = 0; result.v = 0;
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        // this batch: the lowest eight lanes with a ray; group g serves the g-th of them
+        unsigned long long later = todo;
+        for (int i = 0; i < 8 && later; ++i) later &= later - 1;
+        const unsigned long long batch = todo & ~later;
+        todo = later;
+        unsigned long long m = batch;
+        for (int i = 0; i < grp; ++i) m &= m - 1;
+        bool active = m != 0;
+        const int owner = active ? __ffsll((long long)m) - 1 : lane;
+        const F3 o = mk3(__shfl(o_in.x, owner), __shfl(o_in.y, owner), __shfl(o_in.z, owner));
+        const F3 d = mk3(__shfl(d_in.x, owner), __shfl(d_in.y, owner), __shfl(d_in.z, owner));
+        const double tmax = __shfl(tmax_in, owner);
+        const bool any_hit = __shfl(any_hit_in ? 1 : 0, owner) != 0;
+        const F3 dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const bool zero_dir = isinf(dinv.x) || isinf(dinv.y) || isinf(dinv.z);
+        float tcull = tmax >= 3.0e38 ? 3.4e38f : (float)tmax * 1.0000002f;
+        Hit best;
+        best.prim = -1; best.t = tmax; best.u = 0; best.v = 0;
+        int cur = 0, sp = 0;
+        while (__any(active)) {
+            if (active) {
+                const WideChild ch = sc.wide[cur].c[sub];
+                float tn = 0.f;
+                bool hit = false;
+                if (ch.ref != kWideEmpty)
+                    hit = zero_dir ? box_hit_zero_dir(ch.lo, ch.hi, o, d, dinv, tcull, &tn) : box_hit(ch.lo, ch.hi, o, dinv, tcull, &tn);
+                Hit mine = best;
+                mine.prim = -1;
+                if (hit && ch.ref < 0) leaf_test(sc, ~ch.ref, o, d, &mine);
+                // hits of this visit nearer than the best so far, lane by lane
+                unsigned fm = (unsigned)(__ballot(mine.prim >= 0) >> lane0) & 0xffu;
+                while (fm) {
+                    const int l = lane0 + __ffs((int)fm) - 1;
+                    fm &= fm - 1;
+                    const double t = __shfl(mine.t, l), u = __shfl(mine.u, l), v = __shfl(mine.v, l);
+                    const int prim = __shfl(mine.prim, l);
+                    if (t < best.t) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+                }
+                tcull = best.t >= 3.0e38 ? 3.4e38f : (float)best.t * 1.0000002f;
+                if (any_hit && best.prim >= 0) {
+                    active = false;
+                } else {
+                    const bool in = hit && ch.ref >= 0 && tn < tcull;
+                    const unsigned im = (unsigned)(__ballot(in) >> lane0) & 0xffu;
+                    bool got = false;
+                    if (im) {
+                        uint32_t key = in ? ((wide_order_key(tn) & ~7u) | (uint32_t)sub) : 0xffffffffu;
+                        key = min(key, (uint32_t)__shfl_xor((int)key, 1));
+                        key = min(key, (uint32_t)__shfl_xor((int)key, 2));
+                        key = min(key, (uint32_t)__shfl_xor((int)key, 4));
+                        const int near = (int)(key & 7u);
+                        const unsigned others = im & ~(1u << near);
+                        if (in && sub != near) {
+                            const int e = sp + __popc(others & ((1u << sub) - 1u));
+                            col[(e >> 3) * STRIDE + (e & 7)] = ch.ref;
+                            col[((e >> 3) + kStackDepth / 2) * STRIDE + (e & 7)] = __float_as_int(tn);
+                        }
+                        sp += __popc(others);
+                        cur = __shfl(ch.ref, lane0 + near);
+                        got = true;
+                    }
+                    while (!got && sp > 0) {      // the last entry that the best hit has not overtaken
+                        --sp;
+                        const int ref = col[(sp >> 3) * STRIDE + (sp & 7)];
+                        const float tn_e = __int_as_float(col[((sp >> 3) + kStackDepth / 2) * STRIDE + (sp & 7)]);
+                        if (tn_e < tcull) { cur = ref; got = true; }
+                    }
+                    if (!got) active = false;
+                }
+            }
+        }
+        // results to the lanes the rays came from: the r-th lane of the batch reads group r
+        const bool mine_now = (batch >> lane) & 1ull;
+        const int src = __popcll(batch & ((1ull << lane) - 1ull)) << 3;
+        const double t = __shfl(best.t, src & 63), u = __shfl(best.u, src & 63), v = __shfl(best.v, src & 63);
+        const int prim = __shfl(best.prim, src & 63);
+        if (mine_now) { result.t = t; result.u = u; result.v = v; result.prim = prim; }
+    }
+    return result;
+}
+
 // Fills the surface record of a hit: Triangle::intersect :39-48 or
 // Sphere::intersect :39-53, and the object's material / light.
 TKD SurfacePoint surface_at(const DScene& sc, const Hit& h, F3 o, F3 d) {

@@ -88,6 +88,22 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// 256-byte wide node: up to eight descendants of a node of the tree above whose boxes partition its
+// primitives (the node's two children with the largest of them replaced by its own two children, over and
+// over, until there are eight or only leaves are left).  ref >= 0: a wide node; < 0: a leaf as in BvhNode;
+// kWideEmpty: no child.  Eight lanes test the eight boxes of a visit side by side (walk_wide).
+struct WideChild {
+    float lo[3], hi[3];
+    int32_t ref, pad;
+};
+struct WideNode {
+    WideChild c[8];
+};
+static_assert(sizeof(WideNode) == 256, "WideNode must be 256 bytes");
+constexpr int32_t kWideEmpty = INT32_MIN;
+constexpr int kWideRaysDefault = 12;  // measured: 8 .. 16 alike, 24 slower
+constexpr int kWideMaxNodes = 1 << 20;   // larger trees are not collapsed (their passes are bound by throughput, not by their last rays)
+
 // Per-slot triangle record for the intersection test (leaf order).
 struct TriIsect {
     float v0[3], e1[3], e2[3];
@@ -122,6 +138,8 @@ struct DScene {
     const DLight* lights;
     const float* light_cdf;
     int32_t n_tris, n_spheres, n_lights, n_nodes;
+    const WideNode* wide;           // the same tree with eight children per node, or null (not built for this scene)
+    int32_t wide_rays;              // a wave of a path kernel with at most this many rays left walks them in the wide tree
     float bmin[3], bmax[3];
     // Padded bounds of the objects with a specular material (min xyz, max xyz), n_spec_boxes of them; -1:
     // more such objects than kMaxSpecBoxes, no statement.  A light path for the caustic map that misses all
@@ -147,6 +165,9 @@ struct HostBvh {
 // Builds the flat two-children-per-node BVH over triangles followed by spheres.
 void build_bvh(const TkTriangle* tris, int n_tris, const TkSphere* spheres, int n_spheres,
                int max_leaf, int max_stack_depth, HostBvh* out);
+
+// The eight-children form of a two-children tree (WideNode).  Returns the depth of the wide tree.
+int collapse_bvh(const BvhNode* nodes, int n_nodes, std::vector<WideNode>* out);
 
 // The same kind of tree built on the GPU from device arrays (bvh_build_device.hip): nodes and the
 // per-slot triangle records are left in `nodes` / `isect`.
@@ -191,6 +212,9 @@ struct tkhip_ctx {
     float bvh_ms = 0.f;             // wall time of the last build, uploads of its inputs included
     tkd::DScene scene{};
     tkd::DCamera cam{};
+    tkd::DevBuf b_wide;
+    int wide_rays = tkd::kWideRaysDefault;
+    int wide_depth = 0;
     tkd::DevBuf b_nodes, b_tri_isect, b_tri_shade, b_spheres, b_prim_mat, b_mats, b_lights, b_cdf;
     tkd::DevBuf b_dirtab;           // 4 x 256 floats: cosTheta, sinTheta, cosPhi, sinPhi
     tkd::DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e, scratch_f;

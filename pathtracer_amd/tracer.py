@@ -145,6 +145,9 @@ class Context:
               "tkhip_spawn_rays")
         return tuple(outs)
 
+    def set_wide_walk(self, max_rays):
+        check(self.lib, self.lib.tkhip_set_wide_walk(self.h, int(max_rays)), "tkhip_set_wide_walk")
+
     def sample_one_light(self, org, direction, u):
         """Scene::uniformSampleOneLight at the first hit of each ray; u: the four sampler numbers per ray."""
         org, direction, u = _f32(org), _f32(direction), _f32(u)
