@@ -177,7 +177,7 @@ int tkhip_set_bvh_builder(tkhip_ctx* ctx, int mode);
 /* How the last rays of a pass are walked through the BVH (no counterpart in the reference, whose
  * BVHAccel::intersect, src/BVH.cpp:245-288, has one walk).  A wave of a path kernel that is left with at most
  * max_rays rays walks them eight lanes to a ray in a copy of the tree with eight children per node (built by
- * tkhip_set_scene for trees of up to 2^20 nodes): the same boxes, the same primitive tests, the same hit, a third
+ * tkhip_set_scene for trees of up to 2^18 nodes): the same boxes, the same primitive tests, the same hit, a third
  * of the dependent memory round trips.  Default 12; 0: never; 64: every ray begun once the pass's queue is empty, and
  * every ray of tkhip_trace_rays (what the parity tests use).  Takes effect with the next launch. */
 int tkhip_set_wide_walk(tkhip_ctx* ctx, int max_rays);

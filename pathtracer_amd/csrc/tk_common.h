@@ -102,7 +102,9 @@ struct WideNode {
 static_assert(sizeof(WideNode) == 256, "WideNode must be 256 bytes");
 constexpr int32_t kWideEmpty = INT32_MIN;
 constexpr int kWideRaysDefault = 12;  // measured: 8 .. 16 alike, 24 slower
-constexpr int kWideMaxNodes = 1 << 20;   // larger trees are not collapsed (their passes are bound by throughput, not by their last rays)
+// Larger trees are not collapsed: their passes are bound by throughput, not by their last rays, and the collapse
+// (on the host, 3.5 ms for the 76 k nodes of the dragon scene) would take a third of the set-up of a 1 M-triangle scene.
+constexpr int kWideMaxNodes = 1 << 18;
 
 // Per-slot triangle record for the intersection test (leaf order).
 struct TriIsect {
