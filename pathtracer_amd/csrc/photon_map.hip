@@ -980,6 +980,11 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
 #else
 #define TK_STAMP(i)
 #endif
+#ifdef TK_GG_TURNS
+    // turns of phase B as it is (two halves per step), per whole step, per pair of steps, per group; steps; groups; accepted pairs
+    unsigned long long tn_half = 0, tn_step = 0, tn_pair = 0, tn_group = 0, tn_steps = 0, tn_groups = 0, tn_pairs_total = 0;
+    float tn_pair_acc = 0.f, tn_group_acc = 0.f;
+#endif
     Pre cur_q = prefetch((int64_t)uniform_i(gi0));
     while (true) {
         const int64_t g = (int64_t)uniform_i(gi0);
@@ -1138,6 +1143,17 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
                 int wr = cnt;
                 cnt += __popc(m0) + __popc(m1);
                 if (!WANT_IDX && cnt >= k) { m0 = 0; m1 = 0; }   // selected later or handed on: this sum is not needed
+#ifdef TK_GG_TURNS
+                {
+                    const float c1 = (float)__popc(m1), c0 = (float)__popc(m0);
+                    tn_half += (unsigned long long)(wave_max_all(n4 > 32 ? c1 : 0.f) + wave_max_all(c0));
+                    tn_step += (unsigned long long)wave_max_all(c0 + c1);
+                    tn_pair_acc += c0 + c1;
+                    if (((i / kLeavesPerStep) & 1) || i + kLeavesPerStep >= fcount) { tn_pair += (unsigned long long)wave_max_all(tn_pair_acc); tn_pair_acc = 0.f; }
+                    tn_group_acc += c0 + c1;
+                    tn_steps += 1;
+                }
+#endif
                 // B: the set bits of m1 (the first n4 - 32 candidates of a step of more than 32), then of
                 // m0, highest first, i.e. in staging order.  A lane without bits left reads slot 0 and
                 // adds nothing.
@@ -1163,6 +1179,12 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
             }
         }
         TK_STAMP(3)
+#ifdef TK_GG_TURNS
+        tn_group += (unsigned long long)wave_max_all(tn_group_acc);
+        tn_pairs_total += (unsigned long long)wave_sum_all(tn_group_acc);
+        tn_group_acc = 0.f; tn_pair_acc = 0.f;
+        tn_groups += 1;
+#endif
         // Lanes that met k photons or more need a selection.  When they are many (first iterations, dense maps)
         // the whole group is left to the selection kernel, which streams the same leaves again; when they are
         // few they go one by one to the per-query kernel.
@@ -1223,6 +1245,13 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
     if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
     if (sw.met_k && lane == 0 && flagged_sum) atomicAdd(sw.met_k, flagged_sum);
+#ifdef TK_GG_TURNS
+    if (out.photon_sum && lane == 0) {
+        atomicAdd(out.photon_sum + 9, tn_half); atomicAdd(out.photon_sum + 10, tn_step); atomicAdd(out.photon_sum + 11, tn_pair);
+        atomicAdd(out.photon_sum + 12, tn_group); atomicAdd(out.photon_sum + 13, tn_steps); atomicAdd(out.photon_sum + 14, tn_groups);
+        atomicAdd(out.photon_sum + 15, tn_pairs_total);
+    }
+#endif
 #ifdef TK_GG_STAMPS
     // cycles per section, summed over waves: [4] wait for the group index, [5] query load + union box,
     // [6] descent, [7] candidate steps, [8] finish + hand-over (profiling builds only)
