@@ -574,6 +574,11 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
     unsigned long long found_sum = 0;
     for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < total; w += (int64_t)gridDim.x * 4) {
         const int64_t q = list ? (int64_t)list[w] : w;
+#ifdef TK_GW_STAMPS
+        const unsigned long long st_q0 = __builtin_amdgcn_s_memtime();
+        unsigned long long st_a = st_q0;
+        int st_path = 0;
+#endif
         const QLoad Q = load_query(qv, q);
         unsigned long long bound = (unsigned long long)__float_as_uint(Q.r2) << 32;
         float bound_d2 = Q.r2;
@@ -632,6 +637,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                 if (keep) front[cur][__popcll(m & lt_mask)] = node;
                 fcount = __popcll(m);
             }
+#ifdef TK_GW_STAMPS
+            if (gid < 0) st_path = 1;
+#endif
             for (int base = 0; base < n0 && gid < 0; base += 64) {
                 const int node = n0 + base + lane;
                 const bool keep = base + lane < n0 && box_dist2(mv, node, Q.p) < bound_d2;
@@ -655,6 +663,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                 cur ^= 1;
                 fcount = ncount;
             }
+#ifdef TK_GW_STAMPS
+            st_a = __builtin_amdgcn_s_memtime();
+#endif
             if (fits) {
                 // The leaves of the frontier, 64 at a time, nearest first (every lane ranks its leaf's box
                 // distance among the others'), so that the first cut brings the bound close to its final
@@ -738,6 +749,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         // 2. A search region too wide for the frontier (huge radii): depth-first, near child first,
         //    pruning against the bound as it tightens.
         if (!done) {
+#ifdef TK_GW_STAMPS
+            st_path = 2;
+#endif
             count = 0;
             bound = (unsigned long long)__float_as_uint(Q.r2) << 32;
             bound_d2 = Q.r2;
@@ -762,6 +776,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                 }
             }
         }
+#ifdef TK_GW_STAMPS
+        const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
         float r2ret = Q.r2;
         if (count >= k) {
             unsigned long long kmax;
@@ -773,6 +790,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
             }
             r2ret = __uint_as_float((uint32_t)(kmax >> 32));
         }
+#ifdef TK_GW_STAMPS
+        const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+#endif
         float sx = 0, sy = 0, sz = 0;
         for (int e = lane; e < count; e += 64) {
             float4 pw = mv.pow4[pay[e]];
@@ -788,6 +808,20 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
         if (lane == 0) finish_query(out, q, Q, count, r2ret, mk3(sx, sy, sz));
         found_sum += (unsigned long long)count;
+#ifdef TK_GW_STAMPS
+        if (out.photon_sum && lane == 0) {   // profiling build: per way a query took (group leaves / descent / depth first) the slowest, the sum, the count
+            const unsigned long long st_d = __builtin_amdgcn_s_memtime();
+            const unsigned long long dt = st_d - st_q0;
+            atomicMax(out.photon_sum + 4 + st_path, dt);
+            atomicAdd(out.photon_sum + 7 + st_path, dt);
+            atomicAdd(out.photon_sum + 10 + st_path, 1ull);
+            if (st_path == 0) {
+                atomicAdd(out.photon_sum + 13, st_a - st_q0);
+                atomicAdd(out.photon_sum + 14, st_b - st_a);
+                atomicAdd(out.photon_sum + 15, st_c - st_b);
+            }
+        }
+#endif
     }
     if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
     if (out.overflow_sum && list && blockIdx.x == 0 && threadIdx.x == 0)

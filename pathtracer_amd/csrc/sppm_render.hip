@@ -448,7 +448,11 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
-    const bool takes = (int)(threadIdx.x & 63) < lanes_in_use(n);
+    // A queue shorter than the grid is spread over all waves (lanes_in_use); the paths at its front (from
+    // specular surfaces: the long ones) are then dealt thinly too, a few to every wave with the wave's
+    // first fetch, when that leaves a wave few enough of them for the walk with eight lanes to a ray.
+    bool first_fetch = n_front > 0 && a.sc.wide && lanes_in_use(n) < 64 && lanes_in_use(n_front) <= a.sc.wide_rays;
+    bool takes = (int)(threadIdx.x & 63) < (first_fetch ? lanes_in_use(n_front) : lanes_in_use(n));
     bool alive = false, exhausted = false, in_flight = false;
     int slot = 0, bounce = 0, traced = 0;
     PhotonPath P{};
@@ -457,6 +461,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
     while (true) {
         if (!exhausted && __any(!alive && takes)) {
             const int got = wave_fetch_work(&counters[C_QA], !alive && takes, n, &exhausted);
+            if (first_fetch) { first_fetch = false; takes = (int)(threadIdx.x & 63) < lanes_in_use(n); }
             if (got >= 0) {
                 const int at = queue_index(a.q, got, n_front);
                 const float4 ro = a.q.o[at], rd = a.q.d[at], rw = a.q.w[at];
@@ -793,16 +798,29 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     if (!spread && (int64_t)blockIdx.x * 64 >= n) return;   // the waves before this one take the whole queue
-    const bool takes = !spread || (int)(threadIdx.x & 63) < lanes_in_use(n);
+    // spread: the paths at the front of the queue (from specular surfaces: the long ones) are dealt thinly
+    // too, a few to every wave with the wave's first fetch, instead of filling the first waves with them
+    // (when that leaves a wave few enough of them for the walk with eight lanes to a ray)
+    bool first_fetch = spread && n_front > 0 && a.sc.wide && lanes_in_use(n_front) <= a.sc.wide_rays;
+    bool takes = !spread || (int)(threadIdx.x & 63) < (first_fetch ? lanes_in_use(n_front) : lanes_in_use(n));
     bool alive = false, exhausted = false, in_flight = false;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
     CameraPath P{};
     RayWalk w;
     w.cur = kWalkOver;
     const int W = a.cam.w;
+#ifdef TK_CP_STAMPS
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    int st_main_turns = 0, st_wide_turns = 0, st_first_alive = -1, st_at_exhaust = -1;
+#endif
     while (true) {
+#ifdef TK_CP_STAMPS
+        ++st_main_turns;
+        if (exhausted && st_at_exhaust < 0) st_at_exhaust = __popcll(__ballot(alive));
+#endif
         if (!exhausted && __any(!alive && takes)) {
             const int got = wave_fetch_work(&counters[C_QA], !alive && takes, n, &exhausted);
+            if (first_fetch) { first_fetch = false; takes = (int)(threadIdx.x & 63) < lanes_in_use(n); }
             if (got >= 0) {
                 const int at = queue_index(a.q, got, n_front);
                 const float4 ro = a.q.o[at], rd = a.q.d[at], rw = a.q.w[at];
@@ -839,7 +857,14 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
     }
     // The few paths a wave is left with once the queue is empty (none with a ray under way): eight lanes to
     // a ray in the wide tree.  A loop of its own, so that the loop above keeps its registers.
+#ifdef TK_CP_STAMPS
+    const unsigned long long st_mid = __builtin_amdgcn_s_memtime();
+    st_first_alive = __popcll(__ballot(alive));
+#endif
     while (__any(alive)) {
+#ifdef TK_CP_STAMPS
+        ++st_wide_turns;
+#endif
         const Hit h = walk_wide(a.sc, alive, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
         CameraStepOut so{};
         so.want_cq = so.want_gq = false;
@@ -849,6 +874,16 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
         }
         camera_emit_queries(a, counters, so, pixel);
     }
+#ifdef TK_CP_STAMPS
+    if ((threadIdx.x & 63) == 0) {   // profiling build: the slowest wave's times (100 MHz ticks) and turns
+        const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* u = reinterpret_cast<unsigned long long*>(&counters[224]);
+        atomicMax(&u[0], st_mid - st_begin); atomicMax(&u[1], st_end - st_mid);
+        atomicMax(&u[2], (unsigned long long)st_main_turns); atomicMax(&u[3], (unsigned long long)st_wide_turns);
+        atomicMax(&u[4], (unsigned long long)st_first_alive); atomicMax(&u[5], (unsigned long long)(st_at_exhaust + 1));
+        atomicAdd(&u[6], st_end - st_begin); atomicAdd(&u[7], 1ull);
+    }
+#endif
     count_wave_rays(counters, nrays);
 }
 
@@ -1112,6 +1147,9 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)s->n_slots};
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
     TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
+#ifdef TK_CP_STAMPS
+    TK_HIP(hipMemsetAsync(&counters[224], 0, 64, stream));
+#endif
     k_camera_first<<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
     const int waves = s->world > 1 ? std::max(s->path_waves[2] * s->share[2] / 16, 64) : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
     k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
@@ -1128,6 +1166,12 @@ static int camera_trace_wait(tkhip_ctx* ctx) {
     TK_HIP(hipStreamSynchronize(ln.stream));
     s->n_queries[0] = ln.h_counters[C_NGQ];
     s->n_queries[1] = ln.h_counters[C_NCQ];
+    if (getenv("TKHIP_DEBUG_STAMPS")) {   // a profiling build (TK_CP_STAMPS) of k_camera_paths leaves its slowest wave's figures here
+        const unsigned long long* u = reinterpret_cast<const unsigned long long*>(&ln.h_counters[224]);
+        fprintf(stderr, "tkhip: camera paths: slowest main loop %.1f us, wide loop %.1f us, turns %llu / %llu, paths into the wide loop %llu, "
+                "at queue end %lld; mean wave %.1f us of %llu waves\n", u[0] * 0.01, u[1] * 0.01, u[2], u[3], u[4], (long long)u[5] - 1,
+                u[7] ? u[6] * 0.01 / u[7] : 0.0, u[7]);
+    }
     return TKHIP_OK;
 }
 static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
@@ -1812,6 +1856,14 @@ int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset) {
         if (getenv("TKHIP_DEBUG_STAMPS"))   // section cycle sums of a profiling build of the grouped gather kernel
             fprintf(stderr, "tkhip: map %d stamps: launches %lld wait-index %llu load %llu descent %llu steps %llu finish %llu\n", which,
                     (long long)m->group_launches, dev[4], dev[5], dev[6], dev[7], dev[8]);
+        if (getenv("TKHIP_DEBUG_GW"))       // per-query kernel of a profiling build (TK_GW_STAMPS): clock ticks per query by the way it took
+            fprintf(stderr, "tkhip: map %d per-query kernel: from group leaves max %llu mean %.0f n %llu; descent max %llu mean %.0f n %llu; depth first max %llu mean %.0f n %llu\n",
+                    which, dev[4], dev[10] ? (double)dev[7] / dev[10] : 0.0, dev[10], dev[5], dev[11] ? (double)dev[8] / dev[11] : 0.0, dev[11],
+                    dev[6], dev[12] ? (double)dev[9] / dev[12] : 0.0, dev[12]);
+        if (getenv("TKHIP_DEBUG_GW") && dev[10])
+            fprintf(stderr, "tkhip: map %d per-query kernel, from group leaves, mean ticks: leaf list %.0f, steps %.0f, last cut %.0f, sum + update %.0f\n",
+                    which, (double)dev[13] / dev[10], (double)dev[14] / dev[10], (double)dev[15] / dev[10],
+                    ((double)dev[7] - dev[13] - dev[14] - dev[15]) / dev[10]);
         if (getenv("TKHIP_DEBUG_TURNS"))    // phase-B turn counts of a profiling build (TK_GG_TURNS) of the same kernel
             fprintf(stderr, "tkhip: map %d turns: as-is %llu per-step %llu per-pair %llu per-group %llu steps %llu groups %llu accepted %llu\n",
                     which, dev[9], dev[10], dev[11], dev[12], dev[13], dev[14], dev[15]);
