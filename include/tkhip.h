@@ -292,6 +292,19 @@ int tkhip_sppm_camera_begin(tkhip_ctx* ctx, int iter);
  * flux / radius / photon-count update. */
 int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* stats);
 
+/* tkhip_sppm_camera_pass(iter) that also starts the camera paths of iteration
+ * iter + 1 before it gathers, into a second set of query buffers: on a rank of
+ * several, whose share of the paths leaves most of its GPU idle, the next camera
+ * paths (a chain of up to `depth` rays one after the other) run under this
+ * iteration's gathers.  The pixels' radii those paths put into their queries are
+ * stale by one update and are read again when the queries are gathered, so the
+ * result is that of tkhip_sppm_camera_pass(iter) followed by
+ * tkhip_sppm_camera_begin(iter + 1).  The caller commits to iteration iter + 1:
+ * the direct light of its camera paths is already being added to the pixels.
+ * Worker threads of the reference overlap tiles the same way
+ * (src/tracer/TkSppmTracer.cpp:411-438). */
+int tkhip_sppm_camera_pass_ahead(tkhip_ctx* ctx, int iter, TkIterStats* stats);
+
 /* photon_pass + build_maps + camera_pass for world = 1: one state-machine
  * round of SppmTracer::render (src/tracer/TkSppmTracer.cpp:447-541). */
 int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* stats);
@@ -376,10 +389,12 @@ int tkhip_pt_resolve_rgb8(tkhip_ctx* ctx, uint8_t* host_out);
  * copies between the two barriers of an iteration.  devices may name a GPU more
  * than once (a rehearsal of the multi-GPU path on fewer GPUs).
  * set_scene / set_camera / sppm_begin: the call of the same name on every
- * context at once.  sppm_iteration: one iteration on all GPUs; begin_next != 0
+ * context at once.  sppm_iteration: one iteration on all GPUs; begin_next 1
  * also enqueues the light paths of iteration iter + 1 behind the exchange, under
- * this iteration's gathers (pass 0 on the last iteration); stats is null or
- * one TkIterStats per rank.  sppm_merge copies every rank's pixel rows into the
+ * this iteration's gathers; begin_next 2 starts its camera paths as well
+ * (tkhip_sppm_camera_pass_ahead: the caller commits to iteration iter + 1, and
+ * the pixels are in between two iterations until it has run); pass 0 on the last
+ * iteration; stats is null or one TkIterStats per rank.  sppm_merge copies every rank's pixel rows into the
  * context of rank 0 (tkhip_group_ctx(g, 0)), on which tkhip_sppm_resolve_rgb8,
  * tkhip_sppm_read_pixels and tkhip_sppm_preview then see the whole image; the
  * render can go on afterwards. */

@@ -107,6 +107,7 @@ TKHIP_SYMBOLS = {
     "tkhip_sppm_photon_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_sppm_gather_totals": (C.c_int, [C.c_void_p, C.POINTER(TkGatherTotals), C.c_int]),
     "tkhip_sppm_camera_pass": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
+    "tkhip_sppm_camera_pass_ahead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_iteration": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TkIterStats)]),
     "tkhip_sppm_read_pixels": (C.c_int, [C.c_void_p, C.POINTER(TkSPPMPixel)]),
     "tkhip_sppm_export_planes": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -140,8 +140,14 @@ struct SppmState {
     // stays free for the small kernels between the passes; measured at rank 0 of 2: 4.55 -> 3.6 ms.
     int share[3] = {2, 3, 10};
     int path_waves[3] = {0, 0, 0};   // resident waves of the path kernel of each lane when it has the GPU to itself
-    DevBuf qbuf[2];
-    int64_t n_queries[2] = {0, 0};   // global / caustic queries of the last camera trace
+    // Gather queries, global / caustic.  Two sets: a camera pass begun ahead (tkhip_sppm_camera_pass_ahead)
+    // writes the one while the gathers of the iteration before still read the other; the second set is
+    // allocated when it is first needed.
+    DevBuf qbuf[2][2];
+    int camera_set = 0;              // the set the camera pass launched last writes
+    int gather_set = 0;              // the set of the camera pass waited for last: what the gathers read
+    bool stale_radius[2] = {false, false};   // the set was written before the gathers of the iteration before had updated the radii
+    int64_t n_queries[2] = {0, 0};   // global / caustic queries of the camera pass waited for last
     bool pt_mode = false;            // path tracer (tkhip_pt_*): the pixel planes are the film
     int pt_next_sample = 0;
     // hash-grid variant (tkhip_hsppm_*)
@@ -887,6 +893,13 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
     count_wave_rays(counters, nrays);
 }
 
+// The search radius of every query of one map, read again from its pixel (plane = the map's radius plane).
+__global__ void k_query_radius(float4* q0, const float4* q2, int64_t nq, const float* radius2) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    q0[i].w = radius2[__float_as_int(q2[i].w)];
+}
+
 // Final colour + gamma + RGB8, rows bottom-up (src/tracer/TkSppmTracer.cpp:514-529)
 __global__ void k_resolve(const float* planes, int64_t np, int W, int H, int num_recurse, float shoot_g,
                           float shoot_c, int caustic_stored, uint8_t* out) {
@@ -951,7 +964,7 @@ void destroy_sppm(tkhip_ctx* ctx) {
     if (!s) return;
     for (int w = 0; w < 2; ++w) {
         if (s->map[w]) map_destroy(s->map[w]);
-        s->loc_pos[w].release(); s->loc_pow[w].release(); s->loc_dir[w].release(); s->qbuf[w].release();
+        s->loc_pos[w].release(); s->loc_pow[w].release(); s->loc_dir[w].release(); s->qbuf[0][w].release(); s->qbuf[1][w].release();
     }
     s->planes.release();
     s->rows.release();
@@ -1120,12 +1133,12 @@ static int install_local(tkhip_ctx* ctx, int which) {
 // planes, gather queries into the two query buffers.  The photon maps are not
 // read here, so this runs beside the photon passes.  expect_caustic: emit
 // caustic queries (they are dropped later if the caustic map stays empty).
-static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
+static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic, bool ahead = false) {
     SppmState* s = ctx->sppm;
+    s->stale_radius[s->camera_set] = ahead;   // ahead: the gathers of the iteration before have not updated the radii yet
     Lane& ln = s->lane[2];
     hipStream_t stream = ln.stream;
     int32_t* counters = ln.counters.as<int32_t>();
-    s->n_queries[0] = s->n_queries[1] = 0;
     s->camera_in_flight = iter;
     if (s->n_slots == 0) return TKHIP_OK;
     CameraArgs a;
@@ -1141,8 +1154,8 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     a.ld_scale = s->hashgrid ? 1.0f / (float)s->hg_spp : 1.0f;
     a.pt_mode = s->pt_mode ? 1 : 0;
     a.rr = s->rr;
-    a.gq = s->qbuf[0].as<float4>();
-    a.cq = s->qbuf[1].as<float4>();
+    a.gq = s->qbuf[s->camera_set][0].as<float4>();
+    a.cq = s->qbuf[s->camera_set][1].as<float4>();
     a.qcap = s->n_slots;
     a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)s->n_slots};
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
@@ -1162,6 +1175,8 @@ static int camera_trace_wait(tkhip_ctx* ctx) {
     SppmState* s = ctx->sppm;
     Lane& ln = s->lane[2];
     s->camera_in_flight = -1;
+    s->gather_set = s->camera_set;
+    s->n_queries[0] = s->n_queries[1] = 0;
     if (s->n_slots == 0) return TKHIP_OK;
     TK_HIP(hipStreamSynchronize(ln.stream));
     s->n_queries[0] = ln.h_counters[C_NGQ];
@@ -1187,8 +1202,15 @@ static int camera_gather(tkhip_ctx* ctx, int which, bool timed) {
     if (which == 1 && s->stored_c == 0) nq = 0;   // src/tracer/TkSppmTracer.cpp:323
     s->n_queries[which] = nq;
     if (nq == 0) { s->map[which]->last_group_ms = 0.f; s->map[which]->last_overflow = 0; return TKHIP_OK; }
-    float4* q = s->qbuf[which].as<float4>();
+    float4* q = s->qbuf[s->gather_set][which].as<float4>();
     QueryView qv{q, q + s->n_slots, q + 2 * s->n_slots, q + 3 * s->n_slots};
+    if (s->stale_radius[s->gather_set]) {
+        // queries written while the gathers of the iteration before were still to come: their search
+        // radii are the pixels' radii of now (this stream ran those gathers)
+        k_query_radius<<<divup(nq, 256), 256, 0, s->map[which]->stream>>>(q, q + 2 * s->n_slots, nq, s->planes.as<float>() +
+                                                                          (which == 0 ? 12 : 11) * s->n_pixels);
+        TK_LAUNCH_CHECK();
+    }
     GatherOut out{};
     out.planes = s->planes.as<float>();
     out.n_pixels = s->n_pixels;
@@ -1577,7 +1599,7 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
     s->n_slots = (int64_t)s->n_rows * W;
     if (!rc) rc = s->planes.ensure((size_t)s->n_pixels * 13 * 4);
     if (!rc) rc = s->rows.ensure(std::max<size_t>(rows.size(), 1) * 4);
-    for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
+    for (int w = 0; w < 2 && !rc; ++w) rc = s->qbuf[0][w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64);
     for (DevBuf* b : {&s->lane[2].q_o, &s->lane[2].q_d, &s->lane[2].q_w})
         if (!rc) rc = b->ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 16);
     // Everything an iteration would otherwise allocate on first use: the tree and gather scratch of
@@ -1702,24 +1724,45 @@ int tkhip_sppm_set_jitter(tkhip_ctx* ctx, int jitter) {
 int tkhip_sppm_camera_begin(tkhip_ctx* ctx, int iter) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_camera_begin");
     SppmState* s = ctx->sppm;
+    if (s->camera_in_flight == iter) return TKHIP_OK;   // begun ahead by tkhip_sppm_camera_pass_ahead
     if (s->camera_in_flight >= 0) TK_TRY(camera_trace_wait(ctx));
     return camera_trace_launch(ctx, iter, s->prm.causticSize > 0);
 }
 
-int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
-    TK_CTX_SPPM(ctx, "tkhip_sppm_camera_pass");
+static int camera_pass(tkhip_ctx* ctx, int iter, bool next_ahead, TkIterStats* st) {
     SppmState* s = ctx->sppm;
-    TK_REQUIRE(s->map[0]->built, TKHIP_E_STATE, "tkhip_sppm_camera_pass: build the photon maps first");
     double t0 = now_ms();
-    if (s->camera_in_flight == iter) TK_TRY(camera_trace_wait(ctx));   // started by tkhip_sppm_camera_begin
+    if (s->camera_in_flight == iter) TK_TRY(camera_trace_wait(ctx));   // started by tkhip_sppm_camera_begin or ahead
     else {
         if (s->camera_in_flight >= 0) TK_TRY(camera_trace_wait(ctx));
         TK_TRY(camera_trace(ctx, iter, s->prm.causticSize > 0));
     }
     if (st) st->ms_camera += (float)(now_ms() - t0);
-    TK_TRY(gather_both(ctx, st));
     TK_TRY(collect_rays(ctx, 2, st));
+    if (next_ahead) {
+        // The camera paths of the next iteration into the other set of query buffers, before this
+        // iteration's gathers: they read nothing the gathers write except the pixels' radii, which
+        // their queries take again when they are gathered.
+        s->camera_set ^= 1;
+        for (int w = 0; w < 2; ++w) TK_TRY(s->qbuf[s->camera_set][w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64));
+        TK_TRY(camera_trace_launch(ctx, iter + 1, s->prm.causticSize > 0, true));
+    }
+    TK_TRY(gather_both(ctx, st));
     return maybe_preview(ctx, iter, false);
+}
+
+int tkhip_sppm_camera_pass(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_camera_pass");
+    TK_REQUIRE(ctx->sppm->map[0]->built, TKHIP_E_STATE, "tkhip_sppm_camera_pass: build the photon maps first");
+    return camera_pass(ctx, iter, false, st);
+}
+
+int tkhip_sppm_camera_pass_ahead(tkhip_ctx* ctx, int iter, TkIterStats* st) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_camera_pass_ahead");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->map[0]->built, TKHIP_E_STATE, "tkhip_sppm_camera_pass_ahead: build the photon maps first");
+    TK_REQUIRE(!s->hashgrid && !s->pt_mode, TKHIP_E_STATE, "tkhip_sppm_camera_pass_ahead: only for the SPPM tracer with photon maps");
+    return camera_pass(ctx, iter, true, st);
 }
 
 // One iteration on a single GPU.  The camera paths do not read the photon
@@ -1995,7 +2038,7 @@ int tkhip_hsppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     const int64_t nv = s->n_queries[1];
     const uint32_t buckets = (uint32_t)s->n_pixels;
     hipStream_t stream = ctx->stream;
-    const float4* q = s->qbuf[1].as<float4>();
+    const float4* q = s->qbuf[s->gather_set][1].as<float4>();
     const float4 *vp0 = q, *vp1 = q + s->n_slots, *vp2 = q + 2 * s->n_slots, *vp3 = q + 3 * s->n_slots;
     // grid rebuild (src/TkSPPM.cpp:45-86)
     const double t1 = now_ms();

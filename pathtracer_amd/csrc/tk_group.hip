@@ -13,9 +13,10 @@
 //                    peer copies (xGMI is point to point: world-1 independent copies per GPU,
 //                    none of them relayed) and installs them as the two maps;
 //   barrier          everything has been pulled, the ranks' own arrays may be overwritten;
-//   every rank       the light paths of the NEXT iteration are enqueued (they depend on nothing
-//                    this iteration still computes), then the trees are built and the rank's
-//                    queries gathered.
+//   every rank       on request the light paths of the NEXT iteration are enqueued (they depend on
+//                    nothing this iteration still computes); the trees are built; on request the
+//                    camera paths of the next iteration are started (into a second set of query
+//                    buffers); the rank's queries are gathered.
 //
 // No collective library is involved and the host never reads a photon: the
 // counts a rank publishes are the ones its photon pass already holds.
@@ -166,7 +167,7 @@ int aborted() {
 }
 
 // The exchange and the rest of iteration `iter` on rank r; the light paths are in flight or done.
-int rank_iteration(tkhip_group* g, int r, int iter, bool begin_next, TkIterStats* st) {
+int rank_iteration(tkhip_group* g, int r, int iter, int begin_next, TkIterStats* st) {
     tkhip_ctx* ctx = g->ctx[r];
     TK_HIP(hipSetDevice(g->device[r]));
     if (g->next_begun != iter) TK_TRY(tkhip_sppm_photon_begin(ctx, iter));
@@ -200,9 +201,10 @@ int rank_iteration(tkhip_group* g, int r, int iter, bool begin_next, TkIterStats
     for (int w = 0; w < 2; ++w)
         TK_TRY(tkhip_sppm_set_map_photons(ctx, w, B.pos[w].as<float>(), B.pow[w].as<float>(), B.dir[w].as<uint16_t>(), total[w],
                                           shot[w]));
-    if (begin_next) TK_TRY(tkhip_sppm_photon_begin(ctx, iter + 1));
+    if (begin_next >= 1) TK_TRY(tkhip_sppm_photon_begin(ctx, iter + 1));
     TK_TRY(tkhip_sppm_build_maps(ctx, st));
-    TK_TRY(tkhip_sppm_camera_pass(ctx, iter, st));
+    // begin_next 2: the camera paths of iteration iter + 1 are started as well, before this iteration's gathers
+    TK_TRY(begin_next >= 2 ? tkhip_sppm_camera_pass_ahead(ctx, iter, st) : tkhip_sppm_camera_pass(ctx, iter, st));
     return TKHIP_OK;
 }
 
@@ -304,7 +306,7 @@ int tkhip_group_sppm_iteration(tkhip_group* g, int iter, int begin_next, TkIterS
     TK_REQUIRE(g->next_begun < 0 || g->next_begun == iter, TKHIP_E_STATE,
                "tkhip_group_sppm_iteration: the light paths of iteration %d are in flight, not those of %d", g->next_begun, iter);
     if (stats) memset(stats, 0, sizeof(TkIterStats) * (size_t)g->n);
-    int rc = g->run([=](int r) { return rank_iteration(g, r, iter, begin_next != 0, stats ? stats + r : nullptr); });
+    int rc = g->run([=](int r) { return rank_iteration(g, r, iter, begin_next, stats ? stats + r : nullptr); });
     g->next_begun = rc == TKHIP_OK && begin_next ? iter + 1 : -1;
     return rc;
 }

@@ -96,8 +96,8 @@ class HipBackend:
     def camera_begin(self, it):
         check(self.lib, self.lib.tkhip_sppm_camera_begin(self.h, it), "tkhip_sppm_camera_begin")
 
-    def camera_pass(self, it, stats=None):
-        self.tracer.camera_pass(it, stats)
+    def camera_pass(self, it, stats=None, next_ahead=False):
+        self.tracer.camera_pass(it, stats, next_ahead)
 
     def export_planes(self):
         planes = torch.empty((13, self.height, self.width), dtype=torch.float32, device=self.dev)
@@ -200,26 +200,32 @@ def exchange_photons(backend, world):
 
 def iteration(backend, it, world, stats=None, begin_next=False):
     """photon pass -> exchange -> tree builds -> camera pass (gathers), for every rank in lockstep.
-    begin_next: the light paths of iteration it + 1 are enqueued right after the exchange (they depend on
-    nothing this iteration still computes) and run under its tree builds and gathers; the next call must
-    then be for it + 1."""
+    begin_next 1 (or True): the light paths of iteration it + 1 are enqueued right after the exchange (they
+    depend on nothing this iteration still computes) and run under its tree builds and gathers; 2: its camera
+    paths are started as well, before this iteration's gathers (their queries take the pixels' radii again
+    when they are gathered).  The next call must then be for it + 1."""
     if world == 1 and hasattr(backend, "iteration_single"):
         backend.iteration_single(it, stats)
         return [None, None]
+    ahead = int(begin_next) if hasattr(backend, "camera_begin") else 0
     if hasattr(backend, "camera_begin"):
         # camera paths do not read the maps: trace them beside the photon phase, behind the light paths
         # in the GPU's queues (the exchange waits for those)
         if getattr(backend, "_lights_begun", None) != it:
             backend.photon_begin(it)
         backend._lights_begun = None
-        backend.camera_begin(it)
+        backend.camera_begin(it)   # nothing to do when the last call began them ahead
     backend.photon_pass(it, stats)
     totals = exchange_photons(backend, world)
-    if begin_next and hasattr(backend, "camera_begin"):
+    if ahead:
         backend.photon_begin(it + 1)
         backend._lights_begun = it + 1
     backend.build_maps(stats)
-    backend.camera_pass(it, stats)
+    if ahead >= 2:
+        # ... and the camera paths of iteration it + 1 as well, before this iteration's gathers
+        backend.camera_pass(it, stats, next_ahead=True)
+    else:
+        backend.camera_pass(it, stats)
     return totals
 
 

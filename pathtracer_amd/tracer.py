@@ -302,10 +302,13 @@ class SppmTracer:
         check(lib, lib.tkhip_sppm_build_maps(self.ctx.h, C.byref(stats) if stats is not None else None),
               "tkhip_sppm_build_maps")
 
-    def camera_pass(self, it, stats=None):
+    def camera_pass(self, it, stats=None, next_ahead=False):
+        """next_ahead: the camera paths of iteration it + 1 are started before this iteration's gathers
+        (tkhip_sppm_camera_pass_ahead); the caller then has to run iteration it + 1."""
         lib = self.ctx.lib
-        check(lib, lib.tkhip_sppm_camera_pass(self.ctx.h, it, C.byref(stats) if stats is not None else None),
-              "tkhip_sppm_camera_pass")
+        fn = lib.tkhip_sppm_camera_pass_ahead if next_ahead else lib.tkhip_sppm_camera_pass
+        check(lib, fn(self.ctx.h, it, C.byref(stats) if stats is not None else None),
+              "tkhip_sppm_camera_pass_ahead" if next_ahead else "tkhip_sppm_camera_pass")
 
     def iteration(self, it=None, with_stats=True):
         """One Generate -> Rendering round of the state machine (src/tracer/TkSppmTracer.cpp:454-541)."""
@@ -486,7 +489,7 @@ class SppmGroup:
 
     def iteration(self, it, begin_next=False, with_stats=False):
         stats = (_abi.TkIterStats * self.world)() if with_stats else None
-        check(self.lib, self.lib.tkhip_group_sppm_iteration(self.h, it, 1 if begin_next else 0, stats),
+        check(self.lib, self.lib.tkhip_group_sppm_iteration(self.h, it, int(begin_next), stats),
               "tkhip_group_sppm_iteration")
         return stats
 

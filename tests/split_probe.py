@@ -15,7 +15,8 @@ for world in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
     if world == 1:
         be_step = lambda it: be.iteration_single(it)
     else:
-        be_step = lambda it: D.iteration(be, it, world)
+        ahead = int(os.environ.get("SPLIT_PROBE_AHEAD", "0"))   # 0: nothing ahead, 1: the light paths, 2: light and camera paths
+        be_step = lambda it: D.iteration(be, it, world, begin_next=ahead if 5 <= it < 24 else 0)
     for it in range(5):
         be_step(it)
     torch.cuda.synchronize()

@@ -45,16 +45,17 @@ def _oracle_sharded(scene, prm, W, world, iters, seed=0x5EED):
     return merged
 
 
-@pytest.mark.parametrize("world,begin_next", [(2, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,begin_next", [(2, 0), (2, 1), (3, 1), (2, 2), (3, 2)])
 def test_group_iterations_match_the_sharded_oracle(world, begin_next):
     """Ld, photon counts and radii of every pixel bit for bit, fluxes to 1e-5, after three iterations; with
-    begin_next the light paths of iteration i+1 run under the gathers of iteration i and nothing changes."""
+    begin_next 1 the light paths of iteration i+1 run under the gathers of iteration i, with 2 its camera paths
+    as well (second set of query buffers, radii read again at the gather), and nothing changes."""
     scene = Scene.load(asset_scene("cornell_sphere.scene"))
     W, GS, CS, iters = 64, 8000, 1000, 3
     prm = scene.sppm_param(globalSize=GS, causticSize=CS, numRecurse=4)
     grp = SppmGroup(scene, [0] * world, prm, scene.tracer.max_depth, scene.tracer.russian_roulette, W, W)
     for it in range(iters):
-        st = grp.iteration(it, begin_next=begin_next and it + 1 < iters, with_stats=True)
+        st = grp.iteration(it, begin_next=begin_next if it + 1 < iters else 0, with_stats=True)
         assert sum(s.global_stored for s in st) == GS           # the quotas of the ranks make up the map
     got = grp.pixels()
     want = _oracle_sharded(scene, prm, W, world, iters)
