@@ -1779,18 +1779,19 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     TK_REQUIRE(!s->photon_begun, TKHIP_E_STATE, "tkhip_sppm_iteration: finish the photon pass begun with tkhip_sppm_photon_begin first");
     const double t0 = now_ms();
     double t_photon_end[2] = {t0, t0}, build_ms[2] = {0, 0};
-    // Enqueue in the order of the critical path: the camera paths (the longest chain since the light
-    // paths' grids are steered, below), the global pass, the caustic pass.  Each then fills what the
-    // others leave.  (The light paths first: 4.73 instead of 4.69 ms per iteration of cornell_dragon.)
+    // Enqueue in the order of the critical path: the global pass (the longest chain: pass, then
+    // the larger tree), the caustic pass, the camera paths.  Each then fills what the others leave.
+    // (The camera paths first, which the steering below makes the longer chain in steady state:
+    // no change there, 4.71 ms per iteration of cornell_dragon either way, and 2 ms more for the
+    // first iterations of a 16-iteration render.)
     s->caustic_hoff = s->local_shot[0];
     int64_t Bg = 0, Bc = 0;
-    TK_TRY(camera_trace_launch(ctx, iter, s->quota[1] > 0));
+    TK_TRY(photon_pass_begin<0>(ctx, &Bg));
     {
-        int rc1 = photon_pass_begin<0>(ctx, &Bg);
-        if (rc1 == TKHIP_OK) rc1 = photon_pass_begin<1>(ctx, &Bc);
-        if (rc1 != TKHIP_OK) {   // nothing stays in flight behind an error
-            for (Lane& l : s->lane) (void)hipStreamSynchronize(l.stream);
-            s->camera_in_flight = -1;
+        int rc1 = photon_pass_begin<1>(ctx, &Bc);
+        if (rc1 != TKHIP_OK) {   // no batch stays in flight behind an error
+            (void)hipStreamSynchronize(s->lane[0].stream);
+            (void)hipStreamSynchronize(s->lane[1].stream);
             return rc1;
         }
     }
@@ -1818,7 +1819,7 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         }
         return TKHIP_OK;
     });
-    int rc_cam = camera_trace_wait(ctx);
+    int rc_cam = camera_trace(ctx, iter, s->quota[1] > 0);
     const double t_cam = now_ms();
     int rc_g = wg.join();
     int rc_c = wc.join();
