@@ -962,6 +962,11 @@ __global__ void k_unpack_dir(const uint16_t* dir, uint8_t* th, uint8_t* ph, int6
 void destroy_sppm(tkhip_ctx* ctx) {
     SppmState* s = ctx->sppm;
     if (!s) return;
+    // passes begun ahead (tkhip_sppm_photon_begin, tkhip_sppm_camera_begin, tkhip_sppm_camera_pass_ahead) may
+    // still be running: nothing is freed under them
+    for (Lane& l : s->lane)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+    (void)hipStreamSynchronize(ctx->stream);
     for (int w = 0; w < 2; ++w) {
         if (s->map[w]) map_destroy(s->map[w]);
         s->loc_pos[w].release(); s->loc_pow[w].release(); s->loc_dir[w].release(); s->qbuf[0][w].release(); s->qbuf[1][w].release();
@@ -1743,9 +1748,16 @@ static int camera_pass(tkhip_ctx* ctx, int iter, bool next_ahead, TkIterStats* s
         // The camera paths of the next iteration into the other set of query buffers, before this
         // iteration's gathers: they read nothing the gathers write except the pixels' radii, which
         // their queries take again when they are gathered.
-        s->camera_set ^= 1;
-        for (int w = 0; w < 2; ++w) TK_TRY(s->qbuf[s->camera_set][w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64));
-        TK_TRY(camera_trace_launch(ctx, iter + 1, s->prm.causticSize > 0, true));
+        const int other = s->camera_set ^ 1;
+        for (int w = 0; w < 2; ++w) TK_TRY(s->qbuf[other][w].ensure((size_t)std::max<int64_t>(s->n_slots, 1) * 64));
+        s->camera_set = other;
+        const int rc = camera_trace_launch(ctx, iter + 1, s->prm.causticSize > 0, true);
+        if (rc != TKHIP_OK) {   // nothing of the next iteration stays behind: this one can still be gathered by a plain call
+            (void)hipStreamSynchronize(s->lane[2].stream);
+            s->camera_in_flight = -1;
+            s->camera_set = s->gather_set;
+            return rc;
+        }
     }
     TK_TRY(gather_both(ctx, st));
     return maybe_preview(ctx, iter, false);

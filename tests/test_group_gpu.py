@@ -81,6 +81,17 @@ def test_group_of_one_is_the_single_gpu_render():
     tr.close(); grp.close()
 
 
+def test_group_closed_with_the_next_iteration_in_flight():
+    """begin_next 2 leaves the light and camera paths of the next iteration running when the call returns;
+    closing the render then waits for them before anything is freed, and a new render starts clean."""
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    prm = scene.sppm_param(globalSize=8000, causticSize=1000, numRecurse=4)
+    for _ in range(2):
+        grp = SppmGroup(scene, [0, 0], prm, scene.tracer.max_depth, scene.tracer.russian_roulette, 64, 64)
+        grp.iteration(0, begin_next=2)
+        grp.close()
+
+
 def test_group_reports_a_failing_rank():
     lib = _abi.load_tkhip()
     scene = Scene.load(asset_scene("cornell_box.scene"))
