@@ -670,7 +670,12 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
     const F3 wo = neg3(P.d);
     const F3 coef = P.coef;
     F3 Ld = mk3(0, 0, 0);
-    if (has_glossy && sp.light >= 0) Ld = add3(Ld, mul3(coef, light_L(sc.lights[sp.light], sp.n, wo)));
+    // `Ld += coef * Le` and `Ld += coef * uniformSampleOneLight(...)` run at every such hit, with a black
+    // second factor where nothing is emitted or nothing arrives: that adds nothing unless the throughput
+    // has gone non-finite (a reflection at exactly grazing incidence: f = R / 0), in which case the pixel's
+    // direct light turns NaN there as well.  The products with black below keep that.
+    const F3 black = mk3(0.f, 0.f, 0.f);
+    if (has_glossy) Ld = add3(Ld, mul3(coef, sp.light >= 0 ? light_L(sc.lights[sp.light], sp.n, wo) : black));
     bool want_shadow = false;
     F3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 0), ld_light = mk3(0, 0, 0);
     if ((pt || has_glossy || !diffuse) && sc.n_lights > 0) {
@@ -684,6 +689,8 @@ TKD bool camera_on_hit(const CameraArgs& a, int x, int y, int pixel, int bounce,
             sh_o = ls.o; sh_d = ls.d;
             ld_light = mul3(coef, ls.ld);
             want_shadow = true;
+        } else {
+            Ld = add3(Ld, mul3(coef, black));
         }
     }
     // what follows the light sample does not depend on the shadow ray's answer
@@ -739,7 +746,7 @@ TKD bool camera_after_ray(const CameraArgs& a, int x, int y, int pixel, int& bou
                           const Hit& h) {
     if (P.shadow) {
         F3 Ld = P.ld_seen;
-        if (h.prim < 0) Ld = add3(Ld, P.ld_light);
+        Ld = add3(Ld, h.prim < 0 ? P.ld_light : mul3(P.ld_light, mk3(0.f, 0.f, 0.f)));   // blocked: coef * black
         add_direct(a, pixel, Ld, P.flags);
         P.o = P.next_o; P.d = P.next_d; P.coef = P.next_coef; P.flags = P.next_flags;
         P.shadow = false;

@@ -1,7 +1,8 @@
-"""The two large benchmark configurations under test: cornell_dragon with 2 M global + 500 k
-caustic photons per iteration (split eight ways), and the synthetic height field (10 M triangles,
-4096^2, 16 M + 4 M photons).  Each at reduced size against the CPU oracle, and once at full size
-through properties that do not depend on the size."""
+"""The benchmark configurations under test at full size: the three Cornell scenes as their scene files
+configure them (whole 16-iteration renders), cornell_dragon with 2 M global + 500 k caustic photons per
+iteration (split eight ways), and the synthetic height field (10 M triangles, 4096^2, 16 M + 4 M
+photons).  The large two also at reduced size against the CPU oracle; full size goes through properties
+that do not depend on the size."""
 import numpy as np
 import pytest
 
@@ -16,7 +17,12 @@ pytestmark = pytest.mark.gpu
 
 def _pixel_invariants(px, k_g, k_c, r0, iterations):
     """What holds for every SPPMPixel array after `iterations` iterations, whatever the scene."""
-    assert np.isfinite(px).all()
+    # A camera path that meets glass at exactly grazing incidence gets the reference's R / 0 from sample_f and
+    # a NaN throughput, and with it NaN sums for its pixel (tests/test_parity_gpu.py::
+    # test_non_finite_throughput_matches_oracle): a few pixels per million and render at most.
+    bad = ~np.isfinite(px).all(axis=1)
+    assert bad.sum() <= 4 * iterations and np.isfinite(px[:, 9:13]).all()
+    px = px[~bad]
     assert (px[:, 0:9] >= 0).all()                                     # Ld and both fluxes
     cN, gN, cR, gR = px[:, 9], px[:, 10], px[:, 11], px[:, 12]
     assert (cR <= np.float32(r0)).all() and (gR <= np.float32(r0)).all() and (cR > 0).all() and (gR > 0).all()
@@ -60,6 +66,42 @@ def _knn_properties(ctx, pos, power, th, ph, k, rng, nq):
         order = cand[np.lexsort((cand, d2[cand]))][:k]
         assert sorted(order.tolist()) == idx[q][idx[q] >= 0].tolist()
     m.close()
+
+
+# ------------------------------------------------- the three Cornell scenes as configured
+@pytest.mark.parametrize("name,size", [("cornell_box.scene", 512), ("cornell_sphere.scene", 512),
+                                       ("cornell_sphere.scene", 1024), ("cornell_dragon.scene", 1024)])
+def test_cornell_scene_full_size_render(name, size):
+    """A whole render of the scene file's own configuration (200 k global photons, 50 k caustic ones, none in
+    the box scene, k = 100 / 50, 16 iterations) at the benchmark's image size: counters, pixel invariants after
+    the first and the last iteration, radii that only shrink, and an image."""
+    scene = Scene.load(asset_scene(name))
+    prm = scene.tracer.sppm
+    assert prm.globalSize == 200000 and prm.causticSize == (0 if "box" in name else 50000) and prm.numRecurse == 16
+    tr = SppmTracer.from_scene(scene)
+    tr.setScene(scene)
+    tr.setCamera(size, size)
+    tr.startRaytracing()
+    P = size * size
+    radii = None
+    for it in range(16):
+        st = tr.iteration()
+        assert st.global_stored == 200000 and st.caustic_stored == prm.causticSize
+        assert 0 < st.global_paths < 200000 and st.shoot_global >= (it + 1) * 1000
+        assert (st.caustic_paths > prm.causticSize) if prm.causticSize else (st.caustic_paths == 0 and st.gathers_caustic == 0)
+        assert 0.3 * P < st.gathers_global <= P and st.gathers_caustic <= P
+        assert st.gather_photons <= 100 * st.gathers_global + 50 * st.gathers_caustic
+        assert st.rays >= P + st.global_paths       # (caustic light paths that pass by everything specular are not traced)
+        if it in (0, 15):
+            px = tr.pixels()
+            _pixel_invariants(px, 100, 50, 0.08, it + 1)
+            if radii is not None:
+                assert (px[:, 11] <= radii[0]).all() and (px[:, 12] <= radii[1]).all()
+                assert (px[:, 12] < radii[1]).mean() > 0.5          # progressive: most radii have shrunk since iteration 0
+            radii = (px[:, 11].copy(), px[:, 12].copy())
+    img = tr.resolve()
+    assert img.shape == (size, size, 3) and 20 < img.mean() < 235
+    tr.close()
 
 
 # ------------------------------------------------- cornell_dragon, 2 M / 500 k photons

@@ -321,11 +321,16 @@ def _assert_pixels_equal(gpx, opx):
     photons differs), with an absolute floor of 1e-7 of the largest flux for near-black pixels."""
     assert gpx.shape == opx.shape
     g, o = gpx.view(np.uint32), opx.view(np.uint32)
-    assert (g[:, 0:3] == o[:, 0:3]).all(), "Ld"
-    assert (g[:, 9:13] == o[:, 9:13]).all(), "photon counts / radii"
+    # a throughput that went non-finite (a reflection at exactly grazing incidence, f = R / 0) turns a pixel's
+    # sums NaN on both sides, in the same places; which NaN the hardware makes is not compared
+    both_nan = np.isnan(gpx) & np.isnan(opx)
+    assert ((g[:, 0:3] == o[:, 0:3]) | both_nan[:, 0:3]).all(), "Ld"
+    assert ((g[:, 9:13] == o[:, 9:13]) | both_nan[:, 9:13]).all(), "photon counts / radii"
     for lo, hi in ((3, 6), (6, 9)):
         a, b = gpx[:, lo:hi], opx[:, lo:hi]
-        assert (np.abs(a - b) <= 1e-5 * np.abs(b) + 1e-7 * np.abs(b).max()).all(), (lo, float(np.abs(a - b).max()))
+        with np.errstate(invalid="ignore"):
+            close = np.abs(a - b) <= 1e-5 * np.abs(b) + 1e-7 * np.nanmax(np.abs(b))
+        assert (close | both_nan[:, lo:hi]).all(), (lo, float(np.nanmax(np.abs(a - b))))
 
 
 @pytest.mark.parametrize("name,cs", [("cornell_sphere.scene", 3000), ("cornell_box.scene", 0), ("cornell_dragon.scene", 3000)])
@@ -385,6 +390,26 @@ def test_iterations_match_oracle(name, W, cs):
     gi, oi = tr.resolve().astype(int), orr.resolve().astype(int)
     assert np.abs(gi - oi).max() <= 1 and (gi == oi).mean() > 0.999      # powf may differ in its last bit
     assert tr.counters() == orr.counters()
+    tr.close(); orr.close(); osc.close()
+
+
+def test_non_finite_throughput_matches_oracle():
+    """cornell_sphere at 1024^2, full photon counts: in iteration 2 the camera path of pixel (499, 205) touches
+    a sphere so that a specular sample_f divides by AbsDot(wi, N) = 0 (the reflection of the glass,
+    src/core/Material.cpp:64-71, or of the mirror, :90-95, return R / 0): the throughput is inf * 0 = NaN from
+    there on, `Ld += coef * black` at the next hit and the gathers behind it turn the pixel's Ld and both
+    fluxes NaN (src/tracer/TkSppmTracer.cpp:315-318, :325-340).  The reference's arithmetic, reproduced: the same
+    entries are NaN on both sides and every other pixel is equal as usual."""
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    tr, osc, orr = _tracers(scene, 1024, 200000, 50000, 16)
+    for it in range(3):
+        tr.iteration()
+        orr.iteration(it)
+    gpx, opx = tr.pixels(), orr.pixels()
+    assert (np.isnan(gpx) == np.isnan(opx)).all()
+    assert np.isnan(gpx[210419, 0:9]).all() and np.isfinite(gpx[210419, 9:13]).all()
+    assert np.isnan(gpx).any(axis=1).sum() <= 4
+    _assert_pixels_equal(gpx, opx)
     tr.close(); orr.close(); osc.close()
 
 
