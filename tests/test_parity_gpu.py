@@ -410,6 +410,10 @@ def test_non_finite_throughput_matches_oracle():
     assert np.isnan(gpx[210419, 0:9]).all() and np.isfinite(gpx[210419, 9:13]).all()
     assert np.isnan(gpx).any(axis=1).sum() <= 4
     _assert_pixels_equal(gpx, opx)
+    # the resolve clamps with tk::min / tk::max (src/TkMath.h:250-253), which hand a NaN on as the upper bound: white
+    gi, oi = tr.resolve().astype(int), orr.resolve().astype(int)
+    assert np.abs(gi - oi).max() <= 1
+    assert (gi[1024 - 1 - 205, 499] == 255).all()
     tr.close(); orr.close(); osc.close()
 
 
