@@ -393,6 +393,21 @@ def test_iterations_match_oracle(name, W, cs):
     tr.close(); orr.close(); osc.close()
 
 
+@pytest.mark.parametrize("name,size", [("cornell_box.scene", 512), ("cornell_dragon.scene", 1024)])
+def test_full_size_iterations_match_oracle(name, size):
+    """The benchmark configurations themselves (image size and photon counts of the scene file) for two
+    iterations: counters equal, every pixel's Ld, photon counts and radii bit for bit, fluxes to 1e-5."""
+    scene = Scene.load(asset_scene(name))
+    prm = scene.tracer.sppm
+    tr, osc, orr = _tracers(scene, size, prm.globalSize, prm.causticSize, 16)
+    for it in range(2):
+        st, ost = tr.iteration(), orr.iteration(it)
+        for f in ("global_paths", "caustic_paths", "global_stored", "caustic_stored", "gathers_global", "gathers_caustic"):
+            assert getattr(st, f) == getattr(ost, f), (it, f, getattr(st, f), getattr(ost, f))
+    _assert_pixels_equal(tr.pixels(), orr.pixels())
+    tr.close(); orr.close(); osc.close()
+
+
 def test_non_finite_throughput_matches_oracle():
     """cornell_sphere at 1024^2, full photon counts: in iteration 2 the camera path of pixel (499, 205) touches
     a sphere so that a specular sample_f divides by AbsDot(wi, N) = 0 (the reflection of the glass,
