@@ -176,8 +176,8 @@ def main():
     t0 = time.perf_counter()
     last = args.warmup + args.steps - 1
     for it in range(args.warmup, args.warmup + args.steps):
-        # several ranks: the light paths of the next step are enqueued under this step's gathers, as a render
-        # does between its iterations (not after the last one: nothing of step K+1 is left in flight)
+        # several ranks, --ahead 1 / 2: the light paths (and the camera paths) of the next step are begun under
+        # this step's gathers (not after the last one: nothing of step K+1 is left in flight)
         D.iteration(backend, it, world, begin_next=args.ahead if world > 1 and it < last else 0)
     sync()
     elapsed = time.perf_counter() - t0
