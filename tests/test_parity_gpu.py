@@ -408,6 +408,25 @@ def test_full_size_iterations_match_oracle(name, size):
     tr.close(); orr.close(); osc.close()
 
 
+def test_cornell_box_whole_render_matches_oracle():
+    """The first benchmark configuration from end to end: cornell_box at 512^2, 200 k global photons, no caustic
+    map, k = 100, all 16 iterations: the pixel state is compared after every fourth iteration and the resolved
+    images at the end (1 LSB: powf may differ in its last bit)."""
+    scene = Scene.load(asset_scene("cornell_box.scene"))
+    prm = scene.tracer.sppm
+    assert (scene.width, prm.globalSize, prm.causticSize, prm.numRecurse, prm.globalSample) == (512, 200000, 0, 16, 100)
+    tr, osc, orr = _tracers(scene, 512, prm.globalSize, prm.causticSize, prm.numRecurse)
+    for it in range(16):
+        st, ost = tr.iteration(), orr.iteration(it)
+        assert (st.global_paths, st.gathers_global, st.gathers_caustic) == (ost.global_paths, ost.gathers_global, 0)
+        if it % 4 == 3:
+            _assert_pixels_equal(tr.pixels(), orr.pixels())
+    gi, oi = tr.resolve().astype(int), orr.resolve().astype(int)
+    assert np.abs(gi - oi).max() <= 1 and (gi == oi).mean() > 0.999
+    assert tr.counters() == orr.counters()
+    tr.close(); orr.close(); osc.close()
+
+
 def test_non_finite_throughput_matches_oracle():
     """cornell_sphere at 1024^2, full photon counts: in iteration 2 the camera path of pixel (499, 205) touches
     a sphere so that a specular sample_f divides by AbsDot(wi, N) = 0 (the reflection of the glass,
