@@ -257,6 +257,14 @@ def main():
         bytes_launch = bytes_total / launches
         avg_launch_ms = t_ms / (launches / world)   # t_ms is the slowest rank's sum over its own launches
         achieved = bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        # the two maps' launches of a step run side by side: their bytes over the time from the first begin to the last end
+        side = None
+        if world == 1 and gt.steps_side_by_side > 0 and gt.ms_group_side_by_side > 0:
+            side_ms = gt.ms_group_side_by_side / gt.steps_side_by_side
+            side_bw = bytes_total / (gt.ms_group_side_by_side * 1e-3) / 1e9
+            side = {"achieved": side_bw, "frac": side_bw / HBM_PEAK_GBS, "ms_per_step": side_ms,
+                    "note": "both maps' launches of a step together: their algorithmic bytes over the time from the first "
+                            "launch's begin to the last one's end (events on the two streams)"}
         # the same kernel with the GPU to itself (instrumented iterations after the timed region)
         alone_bytes = 96.0 * ((ng - og) + (nc - oc)) + 26.0 * (phot - k_g * og - k_c * oc)
         alone = alone_bytes / (ms_group * 1e-3) / 1e9 if ms_group > 0 else 0.0
@@ -292,6 +300,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "gathers_per_launch": t_q / launches, "finished_per_launch": done / launches,
                          "distance_tests_per_gather": t_staged * 64.0 / max(t_q, 1.0),
+                         "side_by_side": side,
                          "alone": {"achieved": alone, "frac": alone / HBM_PEAK_GBS, "avg_launch_ms": ms_group / 2.0,
                                    "note": "the same kernel with the GPU to itself (instrumented iterations after the "
                                            "timed region, the two maps one after the other)"}},

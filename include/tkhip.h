@@ -260,6 +260,8 @@ typedef struct TkGatherTotals {
     int64_t photons_found_k[2];      /* per map: global, caustic */
     int64_t queries_handed_on_k[2];
     double ms_group_kernel;      /* summed event-timed durations of the launches */
+    double ms_group_side_by_side;    /* the two maps' launches of a step run side by side: first begin to last end, summed over the steps */
+    int64_t steps_side_by_side;      /* steps in that sum */
 } TkGatherTotals;
 int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset);
 

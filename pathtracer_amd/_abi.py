@@ -71,7 +71,8 @@ class TkIterStats(C.Structure):
 class TkGatherTotals(C.Structure):
     _fields_ = [("launches", C.c_int64), ("queries", C.c_int64), ("queries_handed_on", C.c_int64),
                 ("photons_found", C.c_int64), ("photons_staged", C.c_int64), ("photons_found_k", C.c_int64 * 2),
-                ("queries_handed_on_k", C.c_int64 * 2), ("ms_group_kernel", C.c_double)]
+                ("queries_handed_on_k", C.c_int64 * 2), ("ms_group_kernel", C.c_double),
+                ("ms_group_side_by_side", C.c_double), ("steps_side_by_side", C.c_int64)]
 
 
 class TkTracerConfig(C.Structure):

@@ -123,6 +123,9 @@ struct SppmState {
     int64_t n_loc[2] = {0, 0}, last_shot[2] = {0, 0}, local_shot[2] = {0, 0}, shoot[2] = {0, 0};
     int64_t stored_c = 0;
     int64_t last_gather_photons[2] = {0, 0}, last_gather_staged[2] = {0, 0};   // of the last timed gather
+    // the grouped kernels of the two maps side by side: from the first one's begin to the last one's end, summed over the steps
+    double group_union_ms_total = 0.0;
+    int64_t group_union_steps = 0;
     bool photon_begun = false;       // tkhip_sppm_photon_begin has enqueued the first batches
     int64_t begun_batch[2] = {0, 0};
     int camera_in_flight = -1;       // iteration whose camera paths have been launched and not yet waited for
@@ -1299,6 +1302,23 @@ static int gather_both(tkhip_ctx* ctx, TkIterStats* st) {
         w.start(ctx, [ctx]() { return camera_gather(ctx, 1, false); });
         rc = camera_gather(ctx, 0, false);
         rc1 = w.join();
+        // Both streams have drained.  The two grouped kernels ran side by side: the time from the first
+        // one's begin to the last one's end (the events of the two streams share the GPU's clock).
+        tkhip_map *m0 = s->map[0], *m1 = s->map[1];
+        if (rc == TKHIP_OK && rc1 == TKHIP_OK && (m0->ev_pending || m1->ev_pending)) {
+            float d0 = 0.f, d1 = 0.f, b01 = 0.f;
+            bool ok = true;
+            if (m0->ev_pending) ok = ok && hipEventElapsedTime(&d0, m0->ev_begin, m0->ev_end) == hipSuccess;
+            if (m1->ev_pending) ok = ok && hipEventElapsedTime(&d1, m1->ev_begin, m1->ev_end) == hipSuccess;
+            if (m0->ev_pending && m1->ev_pending) ok = ok && hipEventElapsedTime(&b01, m0->ev_begin, m1->ev_begin) == hipSuccess;
+            if (ok) {
+                float span = m0->ev_pending && m1->ev_pending ? std::max(d0, b01 + d1) - std::min(0.f, b01) : (m0->ev_pending ? d0 : d1);
+                s->group_union_ms_total += span;
+                s->group_union_steps += 1;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     }
     if (rc != TKHIP_OK) return rc;
     if (rc1 != TKHIP_OK) return rc1;
@@ -1944,6 +1964,9 @@ int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset) {
             m->group_launches = 0; m->group_queries = 0; m->group_ms_total = 0.0;
         }
     }
+    t.ms_group_side_by_side = s->group_union_ms_total;
+    t.steps_side_by_side = s->group_union_steps;
+    if (reset) { s->group_union_ms_total = 0.0; s->group_union_steps = 0; }
     if (out) *out = t;
     return TKHIP_OK;
 }
