@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
 #ifdef TK_GW_STAMPS
         const unsigned long long st_q0 = __builtin_amdgcn_s_memtime();
         unsigned long long st_a = st_q0;
-        int st_path = 0;
+        int st_path = 0, st_fcount = 0, st_prunes = 0;
 #endif
         const QLoad Q = load_query(qv, q);
         unsigned long long bound = (unsigned long long)__float_as_uint(Q.r2) << 32;
@@ -665,6 +665,7 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
             }
 #ifdef TK_GW_STAMPS
             st_a = __builtin_amdgcn_s_memtime();
+            st_fcount = fcount;
 #endif
             if (fits) {
                 // The leaves of the frontier, 64 at a time, nearest first (every lane ranks its leaf's box
@@ -701,6 +702,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
                         if (acc) { keys[dst] = key; pay[dst] = at; }
                         count += __popcll(m);
                         if (count > CAP - 64) {
+#ifdef TK_GW_STAMPS
+                            ++st_prunes;
+#endif
                             bound = wave_select_prune<EPL>(keys, pay, &count, k, lane, bound_d2, s_hist[wave], s_cand[wave]);
                             bound_d2 = __uint_as_float((uint32_t)(bound >> 32) + 1u);
                         }
@@ -812,7 +816,9 @@ __global__ void __launch_bounds__(256) k_gather_wave(MapView mv, QueryView qv, c
         if (out.photon_sum && lane == 0) {   // profiling build: per way a query took (group leaves / descent / depth first) the slowest, the sum, the count
             const unsigned long long st_d = __builtin_amdgcn_s_memtime();
             const unsigned long long dt = st_d - st_q0;
-            atomicMax(out.photon_sum + 4 + st_path, dt);
+            // the slowest query with its leaf count and the cuts it made on the way, packed behind its ticks
+            atomicMax(out.photon_sum + 4 + st_path, (dt << 20) | ((unsigned long long)(st_fcount < 1023 ? st_fcount : 1023) << 10) |
+                                                        (unsigned long long)(st_prunes < 1023 ? st_prunes : 1023));
             atomicAdd(out.photon_sum + 7 + st_path, dt);
             atomicAdd(out.photon_sum + 10 + st_path, 1ull);
             if (st_path == 0) {

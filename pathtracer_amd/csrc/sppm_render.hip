@@ -2008,9 +2008,11 @@ int tkhip_sppm_gather_totals(tkhip_ctx* ctx, TkGatherTotals* out, int reset) {
             fprintf(stderr, "tkhip: map %d stamps: launches %lld wait-index %llu load %llu descent %llu steps %llu finish %llu\n", which,
                     (long long)m->group_launches, dev[4], dev[5], dev[6], dev[7], dev[8]);
         if (getenv("TKHIP_DEBUG_GW"))       // per-query kernel of a profiling build (TK_GW_STAMPS): clock ticks per query by the way it took
-            fprintf(stderr, "tkhip: map %d per-query kernel: from group leaves max %llu mean %.0f n %llu; descent max %llu mean %.0f n %llu; depth first max %llu mean %.0f n %llu\n",
-                    which, dev[4], dev[10] ? (double)dev[7] / dev[10] : 0.0, dev[10], dev[5], dev[11] ? (double)dev[8] / dev[11] : 0.0, dev[11],
-                    dev[6], dev[12] ? (double)dev[9] / dev[12] : 0.0, dev[12]);
+            fprintf(stderr, "tkhip: map %d per-query kernel: from group leaves max %llu (%llu leaves, %llu cuts) mean %.0f n %llu; descent max %llu (%llu leaves, %llu cuts) mean %.0f n %llu; "
+                    "depth first max %llu mean %.0f n %llu\n",
+                    which, dev[4] >> 20, (dev[4] >> 10) & 1023, dev[4] & 1023, dev[10] ? (double)dev[7] / dev[10] : 0.0, dev[10],
+                    dev[5] >> 20, (dev[5] >> 10) & 1023, dev[5] & 1023, dev[11] ? (double)dev[8] / dev[11] : 0.0, dev[11],
+                    dev[6] >> 20, dev[12] ? (double)dev[9] / dev[12] : 0.0, dev[12]);
         if (getenv("TKHIP_DEBUG_GW") && dev[10])
             fprintf(stderr, "tkhip: map %d per-query kernel, from group leaves, mean ticks: leaf list %.0f, steps %.0f, last cut %.0f, sum + update %.0f\n",
                     which, (double)dev[13] / dev[10], (double)dev[14] / dev[10], (double)dev[15] / dev[10],
