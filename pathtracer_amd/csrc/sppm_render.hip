@@ -302,6 +302,7 @@ struct PhotonArgs {
     float rr;
     int slots;           // staging records per path
     int depth;
+    int defer_below;     // k_photon_first<1>: a wave with at most this many paths left after the cull hands them on untraced
 };
 
 TKD uint64_t halton_index(const PhotonArgs& a, int slot) {
@@ -465,6 +466,7 @@ TKD void count_wave_rays(int32_t* counters, int nrays) {
 // lights, cost about the same and most caustic paths end here (at a diffuse
 // surface), so plain full waves are the efficient shape.  Paths that go on are
 // queued for the second stage.
+constexpr int kUntraced = 0x80;    // flag of a queued light path whose first ray has not been traced yet
 template <int KIND>
 __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int64_t B, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kTraceBlock];
@@ -479,10 +481,17 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
         // a path for the caustic map whose first ray passes by every specular object ends at a diffuse
         // surface or nowhere and stores nothing: it is counted as shot and not traced
         if (KIND == 1 && alive && !may_hit_specular(a.sc, P.o, P.d)) alive = false;
-        if (alive) {
+    }
+    // Where that leaves a wave with a few paths only (a small specular object in a large scene: 3 % of the
+    // paths of the 10 M-triangle field), tracing them here would run the walk for a handful of lanes: they
+    // go to the second stage untraced instead (kUntraced in the flags), where the waves fill up.
+    const bool defer = KIND == 1 && __popcll(__ballot(alive)) <= a.defer_below;
+    if (i < B) {
+        if (alive && !defer) {
             traced = 1;
             alive = photon_step<KIND>(a, (int)i, 0, P, &specular, stk);
         }
+        if (alive && defer) P.flags |= kUntraced;
         if (KIND == 0 && !alive) a.rec_count[i] = P.flags;
     }
     const int at = queue_push(a.q, counters, alive, specular);
@@ -528,8 +537,8 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
                 P.power = mk3(rw.x, rw.y, rw.z);
                 const int packed = __float_as_int(rw.w);
                 slot = packed & 0xffffff;
-                P.flags = packed >> 24;
-                bounce = 1;
+                P.flags = (packed >> 24) & 0x7f;
+                bounce = ((packed >> 24) & kUntraced) ? 0 : 1;   // untraced: the first stage left the path's first ray to this one
                 alive = true;
                 in_flight = false;
             }
@@ -1091,6 +1100,8 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     TK_TRY(ln.rec_offset.ensure((size_t)B * 4));
     PhotonArgs a;
     a.sc = ctx->scene;
+    static const int defer_below = getenv("TKHIP_DEFER_BELOW") ? std::min(std::max(atoi(getenv("TKHIP_DEFER_BELOW")), 0), 64) : 16;   // tuning aid
+    a.defer_below = defer_below;
     TK_TRY(ln.q_o.ensure((size_t)B * 16));
     TK_TRY(ln.q_d.ensure((size_t)B * 16));
     TK_TRY(ln.q_w.ensure((size_t)B * 16));
