@@ -329,8 +329,6 @@ TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
     const float pdf = 1.0f / nl;
     const float u0x = radical_inverse(1, H), u0y = radical_inverse(2, H);
     const float u1x = radical_inverse(3, H), u1y = radical_inverse(4, H);
-    P.ubx = radical_inverse(5, H);
-    P.uby = radical_inverse(6, H);
     const DLight L = sc.lights[li];
     const float upick = photon_rng(a.seed, H, KIND, 0, 0);
     const LightEmission e = light_sample_le(sc, L, u0x, u0y, u1x, u1y, upick);
@@ -340,6 +338,13 @@ TKD bool photon_emit(const PhotonArgs& a, int i, PhotonPath& P) {
     P.d = e.d;
     P.flags = 0;
     return true;
+}
+// The two numbers of the path's BSDF samples (the same two at every bounce, src/tracer/TkSppmTracer.cpp:149, :209);
+// drawn once it is known that the path is traced at all.
+TKD void photon_bsdf_numbers(const PhotonArgs& a, int i, PhotonPath& P) {
+    const uint64_t H = halton_index(a, i);
+    P.ubx = radical_inverse(5, H);
+    P.uby = radical_inverse(6, H);
 }
 
 // One bounce of a light path: closest hit, photon store at diffuse surfaces,
@@ -481,6 +486,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
         // a path for the caustic map whose first ray passes by every specular object ends at a diffuse
         // surface or nowhere and stores nothing: it is counted as shot and not traced
         if (KIND == 1 && alive && !may_hit_specular(a.sc, P.o, P.d)) alive = false;
+        if (alive) photon_bsdf_numbers(a, (int)i, P);
     }
     // Where that leaves a wave with a few paths only (a small specular object in a large scene: 3 % of the
     // paths of the 10 M-triangle field), tracing them here would run the walk for a handful of lanes: they
