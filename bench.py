@@ -12,6 +12,14 @@ process per GPU under torch.distributed.run) the fixed workload is split over
 the ranks (strong scaling): photon paths and pixel rows are sharded, the
 photon maps are all-gathered over RCCL every iteration.
 
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the program
+brings the N ranks up itself: `--driver torch` (default) re-runs itself under
+torch.distributed.run as a child process, before anything here has touched a
+GPU; `--driver group` keeps one process and drives the N GPUs through the
+library's own group entry points (tkhip_group_*: a host thread per GPU, photon
+maps pulled with peer copies, no launcher and no torch in the loop), which is
+how the reference starts its workers (src/core/TkRayTracer.cpp:198-208).
+
 Prints one JSON line on rank 0.
 """
 import argparse
@@ -100,7 +108,23 @@ def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
     }
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(gpus, driver, environ, argv, port=None):
+    """The command that runs this program as `gpus` ranks, or None when this process is to do the work itself:
+    one GPU, a rank that a launcher has already started (WORLD_SIZE set), or the in-process group driver."""
+    if gpus <= 1 or "WORLD_SIZE" in environ or driver != "torch":
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -121,37 +145,268 @@ def main():
     ap.add_argument("--ahead", type=int, default=0, choices=(0, 1, 2),
                     help="N > 1: begin the next iteration's light paths (1) and camera paths (2) under this iteration's gathers; "
                          "a rank alone on a GPU measured 3.50 / 3.71 / 3.99 ms per iteration as rank 0 of 2 and 2.41 / 2.39 / 2.65 as rank 0 of 8")
+    ap.add_argument("--driver", choices=("torch", "group"), default="torch",
+                    help="N > 1: one process per GPU under torch.distributed.run with an RCCL all-gather per iteration (torch), "
+                         "or one process that drives the N GPUs through tkhip_group_* with peer copies (group)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses N > 1 on fewer GPUs")
-    args = ap.parse_args()
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="rehearsal: ranks take GPU (rank mod GPUs present) instead of one GPU each (implied by --backend gloo)")
+    return ap.parse_args(argv)
 
+
+STAT_KEYS = ("rays", "gathers_global", "gathers_caustic", "gather_photons", "overflow_global", "overflow_caustic",
+             "global_paths", "caustic_paths", "group_staged", "rays_camera",
+             # of one more iteration run with the counting instances of the path kernels (tkhip_sppm_set_counting)
+             "node_visits_camera", "prim_tests_camera", "node_visits_light", "prim_tests_light", "counted_rays", "counted_rays_camera")
+COUNT_KEYS = ("node_visits_camera", "prim_tests_camera", "node_visits_light", "prim_tests_light")
+TIME_KEYS = ("ms_gather_kernel", "ms_photon", "ms_build", "ms_camera", "ms_gather")
+
+
+def load_workload(args):
+    from pathtracer_amd.scene import Scene, asset_scene
+    scene = Scene.synthetic(args.synthetic) if args.synthetic else Scene.load(asset_scene(args.scene))
+    name = (f"synthetic height field {args.synthetic}x{args.synthetic} quads ({scene.n_triangles} triangles)"
+            if args.synthetic else args.scene)
+    W = args.size or scene.width
+    H = args.size or scene.height
+    param = scene.sppm_param(globalSize=args.photons[0], causticSize=args.photons[1]) if args.photons else scene.sppm_param()
+    return scene, name, W, H, param
+
+
+def totals_of(lib, ctx_h, reset):
+    from pathtracer_amd import _abi
+    t = _abi.TkGatherTotals()
+    _abi.check(lib, lib.tkhip_sppm_gather_totals(ctx_h, C.byref(t), 1 if reset else 0), "tkhip_sppm_gather_totals")
+    return t
+
+
+def add_counted(acc, counted, n_inst):
+    """Folds the counters of the counting iteration into a rank's sums (scaled so that sum_stats' division by the
+    number of instrumented iterations gives them back)."""
+    for k in COUNT_KEYS:
+        acc[k] = counted[k] * n_inst
+    acc["counted_rays"] = counted["rays"] * n_inst
+    acc["counted_rays_camera"] = counted["rays_camera"] * n_inst
+
+
+def sum_stats(per_rank_dicts, n_inst):
+    """Per-iteration averages of the instrumented iterations: counters summed over the ranks, times of the slowest rank."""
+    vals = {k: sum(d.get(k, 0) for d in per_rank_dicts) / n_inst for k in STAT_KEYS}
+    times = {k: max(d.get(k, 0.0) for d in per_rank_dicts) / n_inst for k in TIME_KEYS}
+    return vals, times
+
+
+def report(args, name, scene, W, H, param, max_depth, rr, seed, world, ranks_seen, driver, elapsed, vals, times, gt,
+           job_ms, iter0_ms, n_job_iters):
+    """The JSON line.  vals / times: sum_stats of the instrumented iterations; gt: the gather totals of the timed
+    region, summed over the ranks (ms_group_kernel: the slowest rank's)."""
+    its = args.steps / elapsed
+    ms_step = elapsed / args.steps * 1e3
+    # Algorithmic bytes of a gather: 56 B query + 26 B per photon found + 40 B pixel slice.
+    # The grouped kernel finishes the gathers that met fewer than k photons; the others end
+    # with exactly k photons in the per-query kernel and are not charged to it here.
+    # Measured over the timed region: every launch of the kernel is bracketed by HIP events on
+    # the stream it runs on (the two maps' launches of a step run side by side there).
+    k_g, k_c = param.globalSample, param.causticSample
+    done = gt["queries"] - gt["handed_on"][0] - gt["handed_on"][1]
+    phot_group = gt["photons_found"] - k_g * gt["handed_on"][0] - k_c * gt["handed_on"][1]
+    bytes_total = 96.0 * done + 26.0 * phot_group
+    launches = max(gt["launches"], 1.0)
+    bytes_launch = bytes_total / launches
+    avg_launch_ms = gt["ms_group_kernel"] / (launches / world)   # the slowest rank's sum over its own launches
+    achieved = bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # the two maps' launches of a step run side by side: their bytes over the time from the first begin to the last end
+    side = None
+    if world == 1 and gt["steps_side_by_side"] > 0 and gt["ms_side_by_side"] > 0:
+        side_bw = bytes_total / (gt["ms_side_by_side"] * 1e-3) / 1e9
+        side = {"achieved": side_bw, "frac": side_bw / HBM_PEAK_GBS, "ms_per_step": gt["ms_side_by_side"] / gt["steps_side_by_side"],
+                "note": "both maps' launches of a step together: their algorithmic bytes over the time from the first "
+                        "launch's begin to the last one's end (events on the two streams)"}
+    ng, nc, og, oc, phot = (vals["gathers_global"], vals["gathers_caustic"], vals["overflow_global"], vals["overflow_caustic"],
+                            vals["gather_photons"])
+    ms_group = times["ms_gather_kernel"]
+    # the same kernel with the GPU to itself (instrumented iterations after the timed region)
+    alone_bytes = 96.0 * ((ng - og) + (nc - oc)) + 26.0 * (phot - k_g * og - k_c * oc)
+    alone = alone_bytes / (ms_group * 1e-3) / 1e9 if ms_group > 0 else 0.0
+    # HBM traffic comes from PMC passes of their own (FETCH_SIZE, WRITE_SIZE), which cannot run inside this
+    # process: the last collection is kept under profiles/ with its provenance.
+    traffic, traffic_note, traffic_camera = None, None, None
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if world == 1 and name == WORKLOAD and not args.size and not args.photons and os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        traffic, traffic_note = tj.get("bytes_per_launch"), tj.get("note")
+        traffic_camera = tj.get("k_camera_paths_bytes_per_launch")
+    out = {
+        "metric": "SPPM iterations/sec", "value": its, "unit": "iterations/s",
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{name} {W}x{H}, {param.globalSize} global + {param.causticSize} caustic photons/iter, "
+                               f"k={k_g}/{k_c}, depth {max_depth}, 1 ray/pixel",
+                   "parallelism": (f"photon paths + pixel rows over {world} GPU(s), " +
+                                   ("photon maps pulled with peer copies (one process, tkhip_group_*)" if driver == "group"
+                                    else "photon all-gather")),
+                   "driver": driver, "photon_tree": args.tree},
+        "mrays_per_s": vals["rays"] / (ms_step * 1e-3) / 1e6,
+        "gathers_per_s": (ng + nc) / (ms_step * 1e-3),
+        "photon_paths_per_s": (vals["global_paths"] + vals["caustic_paths"]) / (ms_step * 1e-3),
+        "phase_ms": {"photon": times["ms_photon"], "kd_build": times["ms_build"], "camera": times["ms_camera"],
+                     "gather": times["ms_gather"], "gather_group_kernel": ms_group},
+        "job_ms": job_ms, "iter0_ms": iter0_ms,
+        "job": (f"{n_job_iters} iterations (the scene's recurse) from startRaytracing to the resolved image, first iteration "
+                f"included, median of {args.jobs} renders; value / ms_per_step are steady-state iterations {args.warmup}.."
+                f"{args.warmup + args.steps - 1}" if job_ms is not None else None),
+        "roofline": {"bound": "hbm", "kernel": "k_gather_group", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                     "launches": launches / world, "avg_launch_ms": avg_launch_ms,
+                     "algorithmic_bytes_per_launch": bytes_launch,
+                     "gathers_per_launch": gt["queries"] / launches, "finished_per_launch": done / launches,
+                     "distance_tests_per_gather": gt["photons_staged"] * 64.0 / max(gt["queries"], 1.0),
+                     "side_by_side": side,
+                     "alone": {"achieved": alone, "frac": alone / HBM_PEAK_GBS, "avg_launch_ms": ms_group / 2.0,
+                               "note": "the same kernel with the GPU to itself (instrumented iterations after the "
+                                       "timed region, the two maps one after the other)"}},
+    }
+    # The whole gather phase (query sort, both gather kernels of both maps, the fused pixel update), from the
+    # instrumented iterations: every gather's 56 B query + 26 B per photon found + 40 B pixel slice.
+    ms_gather = times["ms_gather"]
+    gather_bytes = 96.0 * (ng + nc) + 26.0 * phot
+    gp = gather_bytes / (ms_gather * 1e-3) / 1e9 if ms_gather > 0 else 0.0
+    out["roofline_gather_phase"] = {"bound": "hbm", "kernels": "k_query_bucket / place / rank, k_sort_queries, k_gather_group, k_gather_wave (both maps); in the first iterations also k_query_bound and k_gather_select",
+                                    "achieved": gp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gp / HBM_PEAK_GBS,
+                                    "ms": ms_gather, "algorithmic_bytes": gather_bytes,
+                                    "gathers": ng + nc, "photons_found": phot}
+    # Path kernels: B_ray = 32 B ray + 48 B hit + 64 B per node of the flattened BVH visited (a node holds both
+    # child boxes) + 48 B per primitive tested, the visits and tests counted on the tree that is walked, by a
+    # counting instance of the same kernels on the same rays (the instrumented iterations).  The camera lane's
+    # rays over the time its two kernels take, the light lanes' over theirs (the lanes run side by side).
+    rays_cam, rays_light = vals["rays_camera"], vals["rays"] - vals["rays_camera"]
+    c_cam, c_light = vals["counted_rays_camera"], vals["counted_rays"] - vals["counted_rays_camera"]
+    if rays_cam > 0 and c_cam > 0 and vals["node_visits_camera"] > 0:
+        def lane(rays, counted, nodes, prims, ms, kernels):
+            nodes, prims = nodes / max(counted, 1.0) * rays, prims / max(counted, 1.0) * rays   # per ray of the counted iteration
+            per_ray = 32.0 + 48.0 + 64.0 * nodes / max(rays, 1.0) + 48.0 * prims / max(rays, 1.0)
+            bw = rays * per_ray / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernels": kernels, "rays": rays, "nodes_per_ray": nodes / max(rays, 1.0), "prims_per_ray": prims / max(rays, 1.0),
+                    "bytes_per_ray": per_ray, "ms": ms, "achieved": bw, "frac": bw / HBM_PEAK_GBS}
+        out["roofline_paths"] = {
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "camera": lane(rays_cam, c_cam, vals["node_visits_camera"], vals["prim_tests_camera"], times["ms_camera"],
+                           "k_camera_first, k_camera_paths"),
+            "light": lane(rays_light, c_light, vals["node_visits_light"], vals["prim_tests_light"], times["ms_photon"],
+                          "k_photon_first<0,1>, k_photon_paths<0,1>"),
+            "traffic_k_camera_paths": traffic_camera,
+            "note": "the three lanes run side by side, so each figure is that lane's rays over its own wall time; node visits "
+                    "and primitive tests are counted on the flattened 64-byte-node BVH the kernels walk"}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(scene, W, H, param, max_depth, rr, seed, args.cpu_threads)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+def gt_dict(ts):
+    """Gather totals of the timed region over the ranks (ts: one TkGatherTotals per rank)."""
+    return {"launches": float(sum(t.launches for t in ts)), "queries": float(sum(t.queries for t in ts)),
+            "handed_on": [float(sum(t.queries_handed_on_k[w] for t in ts)) for w in (0, 1)],
+            "photons_found": float(sum(t.photons_found for t in ts)), "photons_staged": float(sum(t.photons_staged for t in ts)),
+            "ms_group_kernel": max(t.ms_group_kernel for t in ts),
+            "ms_side_by_side": ts[0].ms_group_side_by_side, "steps_side_by_side": ts[0].steps_side_by_side}
+
+
+def run_group(args):
+    """N GPUs from this one process: tkhip_group_* (a context and a host thread per GPU inside the library)."""
+    from pathtracer_amd import _abi
+    from pathtracer_amd.tracer import SppmGroup
+    lib = _abi.load_tkhip()
+    present = lib.tkhip_device_count()
+    if present < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    world = args.gpus
+    if present < world and not args.share_gpus:
+        raise SystemExit(f"bench.py --gpus {world} --driver group: {present} GPU(s) present (--share-gpus rehearses on fewer)")
+    devices = [r % present for r in range(world)]
+    scene, name, W, H, param = load_workload(args)
+    max_depth, rr, seed = scene.tracer.max_depth, scene.tracer.russian_roulette, 0x5EED
+    grp = SppmGroup(scene, devices, param, max_depth, rr, W, H, seed=seed)
+    ranks_seen = lib.tkhip_group_size(grp.h)
+    if ranks_seen != world:
+        raise SystemExit(f"bench.py: asked for {world} ranks, the group holds {ranks_seen}")
+    ctxs = [lib.tkhip_group_ctx(grp.h, r) for r in range(world)]
+    for c in ctxs:
+        _abi.check(lib, lib.tkhip_sppm_set_tree(c, 1 if args.tree == "median" else 0), "tkhip_sppm_set_tree")
+    for it in range(args.warmup):
+        grp.iteration(it)        # returns when every rank has finished the iteration
+    for c in ctxs:
+        totals_of(lib, c, True)
+    last = args.warmup + args.steps - 1
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        grp.iteration(it, begin_next=args.ahead if it < last else 0)
+    elapsed = time.perf_counter() - t0
+    gts = [totals_of(lib, c, True) for c in ctxs]
+    n_inst = 3
+    acc = [dict() for _ in range(world)]
+    for it in range(args.warmup + args.steps, args.warmup + args.steps + n_inst):
+        sts = grp.iteration(it, with_stats=True)
+        for r in range(world):
+            d = sts[r].as_dict()
+            acc[r] = {k: acc[r].get(k, 0) + d[k] for k in d}
+    for c in ctxs:
+        _abi.check(lib, lib.tkhip_sppm_set_counting(c, 1), "tkhip_sppm_set_counting")
+    sts = grp.iteration(args.warmup + args.steps + n_inst, with_stats=True)
+    for r in range(world):
+        add_counted(acc[r], sts[r].as_dict(), n_inst)
+    vals, times = sum_stats(acc, n_inst)
+    n_job_iters = num_recurse_of(lib, ctxs[0])
+    grp.close()
+    report(args, name, scene, W, H, param, max_depth, rr, seed, world, ranks_seen, "group", elapsed, vals, times, gt_dict(gts),
+           None, None, n_job_iters)
+
+
+def num_recurse_of(lib, ctx):
+    from pathtracer_amd import _abi
+    nr = C.c_int32()
+    _abi.check(lib, lib.tkhip_sppm_counters(ctx, None, None, C.byref(nr)), "tkhip_sppm_counters")
+    return nr.value
+
+
+def run_ranks(args):
+    """This process is one rank (of WORLD_SIZE, or the only one)."""
     import torch
     import torch.distributed as dist
 
     from pathtracer_amd import _abi
     from pathtracer_amd import distributed as D
-    from pathtracer_amd.scene import Scene, asset_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.backend != "nccl":
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.backend != "nccl" or args.share_gpus:
         local_rank %= max(torch.cuda.device_count(), 1)   # rehearsal: ranks may share a GPU
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if world > 1:
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else "cpu"
+    # every rank that was asked for has come up and takes part in the collectives
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: {ranks_seen} of {world} ranks took part in the all-reduce")
 
-    scene = Scene.synthetic(args.synthetic) if args.synthetic else Scene.load(asset_scene(args.scene))
-    if args.synthetic:
-        args.scene = f"synthetic height field {args.synthetic}x{args.synthetic} quads ({scene.n_triangles} triangles)"
-    W = args.size or scene.width
-    H = args.size or scene.height
-    param = scene.sppm_param(globalSize=args.photons[0], causticSize=args.photons[1]) if args.photons else scene.sppm_param()
+    scene, name, W, H, param = load_workload(args)
     max_depth, rr, seed = scene.tracer.max_depth, scene.tracer.russian_roulette, 0x5EED
     backend = D.HipBackend(scene, param, max_depth, rr, seed, W, H, rank, world, local_rank)
 
@@ -164,15 +419,10 @@ def main():
     lib, ctx_h = backend.lib, backend.h
     _abi.check(lib, lib.tkhip_sppm_set_tree(ctx_h, 1 if args.tree == "median" else 0), "tkhip_sppm_set_tree")
 
-    def gather_totals(reset):
-        t = _abi.TkGatherTotals()
-        _abi.check(lib, lib.tkhip_sppm_gather_totals(ctx_h, C.byref(t), 1 if reset else 0), "tkhip_sppm_gather_totals")
-        return t
-
     for it in range(args.warmup):
         D.iteration(backend, it, world)
     sync()
-    gather_totals(True)   # the grouped gather kernel is event-timed on its stream at every launch: count from here
+    totals_of(lib, ctx_h, True)   # the grouped gather kernel is event-timed on its stream at every launch: count from here
     t0 = time.perf_counter()
     last = args.warmup + args.steps - 1
     for it in range(args.warmup, args.warmup + args.steps):
@@ -181,39 +431,41 @@ def main():
         D.iteration(backend, it, world, begin_next=args.ahead if world > 1 and it < last else 0)
     sync()
     elapsed = time.perf_counter() - t0
-    gt = gather_totals(True)
+    gt = totals_of(lib, ctx_h, True)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # instrumented iterations after the timed region: counters, per-phase and per-kernel device time
-    acc = None
+    acc = {}
     n_inst = 3
     for it in range(args.warmup + args.steps, args.warmup + args.steps + n_inst):
         st = _abi.TkIterStats()
         D.iteration(backend, it, world, st)
         d = st.as_dict()
-        acc = d if acc is None else {k: acc[k] + d[k] for k in d}
+        acc = {k: acc.get(k, 0) + d[k] for k in d}
     sync()
-    vals = torch.tensor([acc["rays"], acc["gathers_global"], acc["gathers_caustic"], acc["gather_photons"],
-                         acc["overflow_global"], acc["overflow_caustic"], acc["global_paths"], acc["caustic_paths"],
-                         acc["group_staged"],
-                         n_inst * gt.queries, n_inst * gt.queries_handed_on_k[0], n_inst * gt.queries_handed_on_k[1],
-                         n_inst * gt.photons_found, n_inst * gt.photons_staged, n_inst * gt.launches, acc["rays_camera"]],
-                        dtype=torch.float64, device=dev)
-    times = torch.tensor([acc["ms_gather_kernel"], acc["ms_photon"], acc["ms_build"], acc["ms_camera"], acc["ms_gather"],
-                          n_inst * gt.ms_group_kernel],
-                         dtype=torch.float64, device=dev)
+    # one more iteration with the counting instances of the path kernels: node visits and primitive tests per ray
+    _abi.check(lib, lib.tkhip_sppm_set_counting(ctx_h, 1), "tkhip_sppm_set_counting")
+    st = _abi.TkIterStats()
+    D.iteration(backend, args.warmup + args.steps + n_inst, world, st)
+    add_counted(acc, st.as_dict(), n_inst)
+    _abi.check(lib, lib.tkhip_sppm_set_counting(ctx_h, 0), "tkhip_sppm_set_counting")
+    sync()
+    gsum = [gt.launches, gt.queries, gt.queries_handed_on_k[0], gt.queries_handed_on_k[1], gt.photons_found, gt.photons_staged]
+    vsum = torch.tensor([acc[k] for k in STAT_KEYS] + gsum, dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([acc[k] for k in TIME_KEYS] + [gt.ms_group_kernel], dtype=torch.float64, device=red_dev)
     if world > 1:
-        if args.backend != "nccl":
-            vals, times = vals.cpu(), times.cpu()
-        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    vals = (vals / n_inst).tolist()
-    times = (times / n_inst).tolist()
-    rays, ng, nc, phot, og, oc, gpaths, cpaths, staged, t_q, t_og, t_oc, t_phot, t_staged, t_launches, rays_cam = vals
-    ms_group, ms_photon, ms_build, ms_camera, ms_gather, t_ms = times
+        dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    vsum, tmax = vsum.tolist(), tmax.tolist()
+    vals = {k: vsum[i] / n_inst for i, k in enumerate(STAT_KEYS)}
+    times = {k: tmax[i] / n_inst for i, k in enumerate(TIME_KEYS)}
+    g = vsum[len(STAT_KEYS):]
+    gtd = {"launches": g[0], "queries": g[1], "handed_on": [g[2], g[3]], "photons_found": g[4], "photons_staged": g[5],
+           "ms_group_kernel": tmax[len(TIME_KEYS)], "ms_side_by_side": gt.ms_group_side_by_side,
+           "steps_side_by_side": gt.steps_side_by_side}
 
     # The job the reference times (src/main.cpp:51-58): a whole render of the scene's own iteration count,
     # first iteration included, from startRaytracing to the resolved image.  Repeated so that the GPU leg of
@@ -224,7 +476,6 @@ def main():
         backend.close()
         jobs, firsts = [], []
         for _ in range(args.jobs):
-            t_a = time.perf_counter()
             backend = D.HipBackend(scene, param, max_depth, rr, seed, W, H, rank, world, local_rank)
             _abi.check(backend.lib, backend.lib.tkhip_sppm_set_tree(backend.h, 1 if args.tree == "median" else 0), "tkhip_sppm_set_tree")
             t_b = time.perf_counter()
@@ -242,102 +493,30 @@ def main():
         backend = None
 
     if rank == 0:
-        its = args.steps / elapsed
-        ms_step = elapsed / args.steps * 1e3
-        # Algorithmic bytes of a gather: 56 B query + 26 B per photon found + 40 B pixel slice.
-        # The grouped kernel finishes the gathers that met fewer than k photons; the others end
-        # with exactly k photons in the per-query kernel and are not charged to it here.
-        # Measured over the timed region: every launch of the kernel is bracketed by HIP events on
-        # the stream it runs on (the two maps' launches of a step run side by side there).
-        k_g, k_c = param.globalSample, param.causticSample
-        done = t_q - t_og - t_oc
-        phot_group = t_phot - k_g * t_og - k_c * t_oc
-        bytes_total = 96.0 * done + 26.0 * phot_group
-        launches = max(t_launches, 1.0)
-        bytes_launch = bytes_total / launches
-        avg_launch_ms = t_ms / (launches / world)   # t_ms is the slowest rank's sum over its own launches
-        achieved = bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        # the two maps' launches of a step run side by side: their bytes over the time from the first begin to the last end
-        side = None
-        if world == 1 and gt.steps_side_by_side > 0 and gt.ms_group_side_by_side > 0:
-            side_ms = gt.ms_group_side_by_side / gt.steps_side_by_side
-            side_bw = bytes_total / (gt.ms_group_side_by_side * 1e-3) / 1e9
-            side = {"achieved": side_bw, "frac": side_bw / HBM_PEAK_GBS, "ms_per_step": side_ms,
-                    "note": "both maps' launches of a step together: their algorithmic bytes over the time from the first "
-                            "launch's begin to the last one's end (events on the two streams)"}
-        # the same kernel with the GPU to itself (instrumented iterations after the timed region)
-        alone_bytes = 96.0 * ((ng - og) + (nc - oc)) + 26.0 * (phot - k_g * og - k_c * oc)
-        alone = alone_bytes / (ms_group * 1e-3) / 1e9 if ms_group > 0 else 0.0
-        # HBM traffic of the kernel comes from PMC passes of their own (FETCH_SIZE, WRITE_SIZE), which cannot
-        # run inside this process: the last collection is kept under profiles/ with its provenance.
-        traffic, traffic_note = None, None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if world == 1 and args.scene == WORKLOAD and not args.size and os.path.exists(tp):
-            with open(tp) as f:
-                tj = json.load(f)
-            traffic, traffic_note = tj.get("bytes_per_launch"), tj.get("note")
-        out = {
-            "metric": "SPPM iterations/sec", "value": its, "unit": "iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.scene} {W}x{H}, {param.globalSize} global + {param.causticSize} caustic photons/iter, "
-                                   f"k={k_g}/{k_c}, depth {max_depth}, 1 ray/pixel",
-                       "parallelism": f"photon paths + pixel rows over {world} GPU(s), photon all-gather",
-                       "photon_tree": args.tree},
-            "mrays_per_s": rays / (ms_step * 1e-3) / 1e6,
-            "gathers_per_s": (ng + nc) / (ms_step * 1e-3),
-            "photon_paths_per_s": (gpaths + cpaths) / (ms_step * 1e-3),
-            "phase_ms": {"photon": ms_photon, "kd_build": ms_build, "camera": ms_camera, "gather": ms_gather,
-                         "gather_group_kernel": ms_group},
-            "job_ms": job_ms, "iter0_ms": iter0_ms,
-            "job": (f"{n_job_iters} iterations (the scene's recurse) from startRaytracing to the resolved image, first iteration "
-                    f"included, median of {args.jobs} renders; value / ms_per_step are steady-state iterations {args.warmup}.."
-                    f"{args.warmup + args.steps - 1}" if job_ms is not None else None),
-            "roofline": {"bound": "hbm", "kernel": "k_gather_group", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "launches": launches / world, "avg_launch_ms": avg_launch_ms,
-                         "algorithmic_bytes_per_launch": bytes_launch,
-                         "gathers_per_launch": t_q / launches, "finished_per_launch": done / launches,
-                         "distance_tests_per_gather": t_staged * 64.0 / max(t_q, 1.0),
-                         "side_by_side": side,
-                         "alone": {"achieved": alone, "frac": alone / HBM_PEAK_GBS, "avg_launch_ms": ms_group / 2.0,
-                                   "note": "the same kernel with the GPU to itself (instrumented iterations after the "
-                                           "timed region, the two maps one after the other)"}},
-        }
-        # The whole gather phase (query sort, both gather kernels of both maps, the fused pixel update), from the
-        # instrumented iterations: every gather's 56 B query + 26 B per photon found + 40 B pixel slice.
-        gather_bytes = 96.0 * (ng + nc) + 26.0 * phot
-        gp = gather_bytes / (ms_gather * 1e-3) / 1e9 if ms_gather > 0 else 0.0
-        out["roofline_gather_phase"] = {"bound": "hbm", "kernels": "k_query_bucket / place / rank, k_sort_queries, k_gather_group, k_gather_wave (both maps); in the first iterations also k_query_bound and k_gather_select",
-                                        "achieved": gp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gp / HBM_PEAK_GBS,
-                                        "ms": ms_gather, "algorithmic_bytes": gather_bytes,
-                                        "gathers": ng + nc, "photons_found": phot}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, param, max_depth, rr, seed, args.cpu_threads)
-            # Path kernels: B_ray = 32 B ray + 48 B hit + 32 B per box test + 48 B per primitive test, the tests
-            # per ray counted by the CPU port on the same rays (implementation independent); the camera lane's
-            # rays over the time its two kernels take, the light lanes' over theirs (the lanes run side by side).
-            pr = out["cpu_baseline"]["per_ray"]
-            def b_ray(c):
-                return 32.0 + 48.0 + 32.0 * c["box_tests_per_ray"] + 48.0 * c["prim_tests_per_ray"]
-            cam = rays_cam * b_ray(pr["tc_camera"]) / (ms_camera * 1e-3) / 1e9 if ms_camera > 0 else 0.0
-            lig = (rays - rays_cam) * b_ray(pr["tc_photon"]) / (ms_photon * 1e-3) / 1e9 if ms_photon > 0 else 0.0
-            out["roofline_paths"] = {
-                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "camera": {"kernels": "k_camera_first, k_camera_paths", "rays": rays_cam, "bytes_per_ray": b_ray(pr["tc_camera"]),
-                           "ms": ms_camera, "achieved": cam, "frac": cam / HBM_PEAK_GBS},
-                "light": {"kernels": "k_photon_first<0,1>, k_photon_paths<0,1>", "rays": rays - rays_cam,
-                          "bytes_per_ray": b_ray(pr["tc_photon"]), "ms": ms_photon, "achieved": lig, "frac": lig / HBM_PEAK_GBS},
-                "note": "the three lanes run side by side, so each figure is that lane's rays over its own wall time"}
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        report(args, name, scene, W, H, param, max_depth, rr, seed, world, ranks_seen, "torch", elapsed, vals, times, gtd,
+               job_ms, iter0_ms, n_job_iters)
     if backend is not None:
         backend.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    cmd = launcher_command(args.gpus, args.driver, os.environ, argv)
+    if cmd is not None:
+        # Nothing in this process has touched a GPU (torch is not even imported): the ranks are children of
+        # the launcher, and this process only passes their output and exit status on.
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    if args.gpus > 1 and args.driver == "group" and "WORLD_SIZE" not in os.environ:
+        run_group(args)
+    else:
+        run_ranks(args)
 
 
 if __name__ == "__main__":

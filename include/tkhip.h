@@ -131,6 +131,13 @@ typedef struct TkIterStats {
     float ms_gather_kernel;   /* the dominant (grouped) gather kernel only          */
     float ms_total;
     int64_t rays_camera;      /* of `rays`: those of the camera paths (the rest are light paths) */
+    /* Filled only while tkhip_sppm_set_counting is on: what those rays cost on the flattened BVH that is   */
+    /* walked (BVHAccel::intersect, src/BVH.cpp:245-288): nodes fetched (a node holds both child boxes, 64  */
+    /* bytes; a node of the eight-children copy counts as four) and primitives tested (48 bytes each).      */
+    int64_t node_visits_camera;
+    int64_t prim_tests_camera;
+    int64_t node_visits_light;
+    int64_t prim_tests_light;
 } TkIterStats;
 
 typedef struct tkhip_ctx tkhip_ctx;
@@ -222,6 +229,22 @@ int tkhip_sppm_export_local_photons(tkhip_ctx* ctx, int which, float* pos, float
 int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, const float* power,
                                const uint16_t* dir, int64_t n, int64_t shot_total);
 
+/* The same exchange without the host in it, for a driver that moves ONE buffer per rank with one collective
+ * (an all-gather): no counterpart in the reference, whose threads share one PhotonMap behind a mutex
+ * (src/tracer/TkSppmTracer.cpp:139-141).  A rank's buffer is *words_per_rank 32-bit words (the same on every
+ * rank): a header with its photon counts and shot counters, then both maps' arrays.
+ * tkhip_sppm_export_exchange writes this rank's buffer (DEVICE memory) on the caller's stream (a hipStream_t,
+ * 0 = the null stream) and does not wait: the collective the caller enqueues behind it on that stream is
+ * ordered, and the rank's next photon pass waits for the copies by an event.
+ * tkhip_sppm_import_exchange takes all ranks' buffers back to back (world * words_per_rank words, DEVICE, as
+ * the all-gather delivers them on `stream`) and installs both maps on the device: the counts come from the
+ * headers there, the host assumes that every rank met its quota and enqueues the builds at once;
+ * tkhip_sppm_build_maps then checks that assumption against what the device summed (and rebuilds a map that
+ * came out smaller), and adds the ranks' shot counters to the cumulative ones. */
+int tkhip_sppm_exchange_words(tkhip_ctx* ctx, int64_t* words_per_rank);
+int tkhip_sppm_export_exchange(tkhip_ctx* ctx, int32_t* device_buf, void* stream);
+int tkhip_sppm_import_exchange(tkhip_ctx* ctx, const int32_t* device_gathered, void* stream);
+
 /* PhotonMap::buildKdTree for both maps (src/tracer/Photonmap.cpp:96-103,
  * :132-179): the search tree of each map, here a balanced binary tree over the
  * photons in Hilbert-curve order with tight boxes (a gather's result does not
@@ -280,6 +303,12 @@ int tkhip_sppm_photon_begin(tkhip_ctx* ctx, int iter);
  * src/core/sampler.cpp:51, :61-62).  With jitter 0 nothing random is left in a
  * camera pass. */
 int tkhip_sppm_set_jitter(tkhip_ctx* ctx, int jitter);
+
+/* on != 0: from the next pass on the path kernels run as counting instances (the same code with two
+ * more counters per lane) and TkIterStats reports node_visits_* / prim_tests_*, the figures the ray
+ * roofline is priced with.  Results are unchanged; the passes get slower, so timings are taken with
+ * counting off.  Counts what BVHAccel::intersect does per ray (src/BVH.cpp:245-288) on this tree. */
+int tkhip_sppm_set_counting(tkhip_ctx* ctx, int on);
 
 /* Starts the camera paths of iteration `iter` (the part of traceTile that does
  * not read the photon maps, src/tracer/TkSppmTracer.cpp:296-321, :341-371) and
@@ -468,8 +497,10 @@ int tkhip_map_gather(tkhip_map* map, int64_t nq, const float* p, const float* n,
                      float* radius2_out, int32_t* idx, int mode);
 
 /* tkhip_map_gather (production path, mode 0) for callers that cannot allocate
- * device memory: code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  No counterpart in the reference.  Every array is a
+ * device memory: tight serving loops, harnesses that forbid hipMalloc, code
+ * that must not disturb an allocator another library owns.  (Not for use while
+ * a stream is being captured into a HIP graph: the call synchronises its
+ * stream before it returns.)  No counterpart in the reference.  Every array is a
  * DEVICE pointer (same shapes as tkhip_map_gather; idx may be null); the query
  * order, the hand-over list between the two gather kernels and the sort's
  * temporary storage live in one static device array of
@@ -478,7 +509,7 @@ int tkhip_map_gather(tkhip_map* map, int64_t nq, const float* p, const float* n,
  * queries per call (TKHIP_E_LIMIT beyond).  All calls on one GPU share that
  * array: calls that overlap on one GPU race and must be serialised by the
  * caller.  Work is enqueued on the map's stream; the call returns after it has
- * finished. */
+ * finished.  It takes no part in the timing totals of tkhip_sppm_gather_totals. */
 #define TKHIP_STATIC_MAX_QUERIES 65536
 #define TKHIP_STATIC_SCRATCH_BYTES (12 << 20)
 int tkhip_map_gather_static(tkhip_map* map, int64_t nq, const float* p, const float* n, const float* wo,

@@ -62,7 +62,9 @@ class TkIterStats(C.Structure):
                 ("group_staged", C.c_int64),
                 ("ms_photon", C.c_float), ("ms_build", C.c_float), ("ms_camera", C.c_float),
                 ("ms_gather", C.c_float), ("ms_gather_kernel", C.c_float), ("ms_total", C.c_float),
-                ("rays_camera", C.c_int64)]
+                ("rays_camera", C.c_int64),
+                ("node_visits_camera", C.c_int64), ("prim_tests_camera", C.c_int64),
+                ("node_visits_light", C.c_int64), ("prim_tests_light", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -159,6 +161,10 @@ TKHIP_SYMBOLS = {
     "tkhip_sample_le": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                   c_float_p, c_float_p, c_float_p, c_float_p]),
     "tkhip_sppm_set_jitter": (C.c_int, [C.c_void_p, C.c_int]),
+    "tkhip_sppm_exchange_words": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "tkhip_sppm_export_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tkhip_sppm_import_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tkhip_sppm_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "tkhip_stratified_samples": (C.c_int, [C.c_void_p, C.c_int64, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                            C.c_int, c_uint8_p, C.c_int, C.c_uint64, c_float_p]),
     "tkhip_spawn_rays": (C.c_int, [C.c_void_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,

@@ -39,6 +39,7 @@ struct GatherScratch {
     float* q_r2s;                    // per query slot: the radius^2 to search with (the query's own or a smaller bound)
     int heavy;                       // many gathers of the map's last launch met k photons (or no launch yet): radii are cut first
     int track;                       // count the gathers of this launch that meet k photons (counter[24]) for the next decision
+    int untimed;                     // no events around the grouped kernel and nothing added to the map's running totals
     int32_t* counter;            // 32 ints, cleared per gather: [0] the hand-over count, [16] the selection kernel's groups, [24] gathers that met k photons
     void* sort_temp;
     size_t sort_temp_bytes;

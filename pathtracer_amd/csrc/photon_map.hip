@@ -1953,8 +1953,10 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), group_grid_blocks(m->ctx->device));
     int32_t* scount = sc.counter + 16;     // groups left to the selection kernel
     TK_HIP(hipMemsetAsync(ocount, 0, 128, s));
-    TK_TRY(map_flush_timing(m));
-    TK_HIP(hipEventRecord(m->ev_begin, s));
+    if (!sc.untimed) {
+        TK_TRY(map_flush_timing(m));
+        TK_HIP(hipEventRecord(m->ev_begin, s));
+    }
     const GroupLeaves gl{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
     // (the two thresholds can be forced from the environment: tests run every gather through the selection kernel)
     static const int sel_min_env = getenv("TKHIP_SEL_MIN") ? atoi(getenv("TKHIP_SEL_MIN")) : 0;
@@ -1968,7 +1970,7 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     else
         k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
     TK_LAUNCH_CHECK();
-    TK_HIP(hipEventRecord(m->ev_end, s));
+    if (!sc.untimed) TK_HIP(hipEventRecord(m->ev_end, s));
     // the groups with many lanes at k or above (their number is known to the device only: the waves of a
     // grid that fills the GPU once share them out)
     const int sel_blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), select_grid_blocks(m->ctx->device));
@@ -1979,9 +1981,11 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
             k_gather_select<false><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
         TK_LAUNCH_CHECK();
     }
-    m->ev_pending = true;
-    m->group_queries += nq;
-    if (timed) {
+    if (!sc.untimed) {
+        m->ev_pending = true;
+        m->group_queries += nq;
+    }
+    if (timed && !sc.untimed) {
         TK_HIP(hipEventSynchronize(m->ev_end));
         TK_HIP(hipEventElapsedTime(&m->last_group_ms, m->ev_begin, m->ev_end));
     }
@@ -2213,6 +2217,7 @@ int tkhip_map_gather_static(tkhip_map* m, int64_t nq, const float* p, const floa
     sc.q_r2s = reinterpret_cast<float*>(take(Q * 4));
     sc.heavy = 1;      // the array is shared by every map of the GPU: no history, the radii are always bounded
     sc.track = 0;
+    sc.untimed = 1;    // the map's running totals (tkhip_sppm_gather_totals) are those of its render's gathers
     sc.counter = reinterpret_cast<int32_t*>(take(512));
     TK_REQUIRE(at < (size_t)TKHIP_STATIC_SCRATCH_BYTES, TKHIP_E_LIMIT, "tkhip_map_gather_static: scratch layout exceeds the array");
     sc.sort_temp = base + at;

@@ -42,7 +42,7 @@ namespace tkd {
 // 4 % of the iteration.  Everything before kCounterBatchInts is cleared for
 // every batch of a pass; the 64-bit totals behind it run over the whole pass.
 enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 32, C_QD = 64, C_NGQ = 96, C_NCQ = 128, C_TOTAL = 160, C_USED = 161,
-       C_RAYS = 192 /* u64 */, C_PHOT = 194 /* u64 */, C_CAND = 196 /* u64 */ };
+       C_RAYS = 192 /* u64 */, C_NODES = 194 /* u64 */, C_PRIMS = 196 /* u64 */ };   // the last two: counting instances only
 constexpr int kCounterBatchInts = 192;
 constexpr int kCounterBytes = 256 * 4;
 
@@ -116,6 +116,7 @@ struct SppmState {
     float rr = 0.8f;
     uint32_t seed = 0;
     int no_jitter = 0;               // tkhip_sppm_set_jitter
+    bool counting = false;           // tkhip_sppm_set_counting: the passes run the counting instances of their kernels
     int rank = 0, world = 1;
     tkhip_map* map[2] = {nullptr, nullptr};
     int64_t quota[2] = {0, 0};
@@ -157,6 +158,11 @@ struct SppmState {
     bool hashgrid = false;
     int hg_spp = 1;
     DevBuf hg_prm, hg_bounds, hg_count, hg_start, hg_cursor, hg_items, hg_phi, hg_m;
+    // photon exchange between ranks through one buffer per rank (tkhip_sppm_export_exchange / import_exchange)
+    hipEvent_t ev_exchange = nullptr, ev_preview = nullptr;
+    long long* h_exchange = nullptr;         // pinned: per map the photon count and the light paths shot, summed over the ranks
+    bool exchange_pending = false;           // an import has installed maps whose sizes the host has only assumed so far
+    int64_t exchange_expected[2] = {0, 0};
     DevBuf preview;                  // RGBA8 frame buffer on the device (tkhip_sppm_set_preview)
     int preview_every = 0, preview_iter = -1;
 };
@@ -425,9 +431,9 @@ TKD bool may_hit_specular(const DScene& sc, F3 o, F3 d) {
     }
     return false;
 }
-template <int KIND, class STACK>
-TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, bool* specular, STACK stk) {
-    const Hit h = trace_ray(a.sc, P.o, P.d, 1.7976931348623157e308, false, stk);
+template <int KIND, bool COUNT, class STACK>
+TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, bool* specular, STACK stk, WalkCount* wc) {
+    const Hit h = trace_ray_t<COUNT>(a.sc, P.o, P.d, 1.7976931348623157e308, false, stk, wc);
     return photon_on_hit<KIND>(a, slot, bounce, P, h, specular);
 }
 
@@ -465,6 +471,15 @@ TKD void count_wave_rays(int32_t* counters, int nrays) {
     if ((threadIdx.x & 63) == 0 && wr > 0)
         atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_RAYS]), (unsigned long long)wr);
 }
+// Counting instances of the kernels (tkhip_sppm_set_counting): nodes fetched and primitives tested by the wave.
+TKD void count_wave_walk(int32_t* counters, const WalkCount& wc) {
+    int n = wc.nodes, p = wc.prims;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { n += __shfl_xor(n, o2); p += __shfl_xor(p, o2); }
+    if ((threadIdx.x & 63) == 0) {
+        if (n > 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_NODES]), (unsigned long long)n);
+        if (p > 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_PRIMS]), (unsigned long long)p);
+    }
+}
 
 // First stage of the photon pass of a batch of B light paths: emission and the
 // first segment of every path, one path per lane.  These rays all leave the
@@ -472,10 +487,11 @@ TKD void count_wave_rays(int32_t* counters, int nrays) {
 // surface), so plain full waves are the efficient shape.  Paths that go on are
 // queued for the second stage.
 constexpr int kUntraced = 0x80;    // flag of a queued light path whose first ray has not been traced yet
-template <int KIND>
+template <int KIND, bool COUNT = false>
 __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int64_t B, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kTraceBlock];
     LdsStack stk{&s_stack[threadIdx.x]};
+    WalkCount wc{0, 0};
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     bool alive = false, specular = false;
     int traced = 0;
@@ -495,7 +511,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
     if (i < B) {
         if (alive && !defer) {
             traced = 1;
-            alive = photon_step<KIND>(a, (int)i, 0, P, &specular, stk);
+            alive = photon_step<KIND, COUNT>(a, (int)i, 0, P, &specular, stk, &wc);
         }
         if (alive && defer) P.flags |= kUntraced;
         if (KIND == 0 && !alive) a.rec_count[i] = P.flags;
@@ -507,6 +523,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
         a.q.w[at] = make_float4(P.power.x, P.power.y, P.power.z, __int_as_float((int)i | (P.flags << 24)));
     }
     count_wave_rays(counters, traced);
+    if (COUNT) count_wave_walk(counters, wc);
 }
 
 // Second stage: the queued paths from their second segment on.  The grid is
@@ -516,10 +533,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int6
 // (walk_rays) until all but an eighth of them have finished; the lanes whose
 // ray is over take the bounce and start their next ray, the others keep
 // walking theirs in the next turn.
-template <int KIND>
+template <int KIND, bool COUNT = false>
 __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
+    WalkCount wc{0, 0};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     // A queue shorter than the grid is spread over all waves (lanes_in_use); the paths at its front (from
     // specular surfaces: the long ones) are then dealt thinly too, a few to every wave with the wave's
@@ -561,7 +579,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
             in_flight = true;
             ++traced;
         }
-        walk_rays(a.sc, w, P.o, P.d, false, stk, last ? 0 : n_alive >> kWalkRestShift);   // last: the rays under way are finished, none begun
+        walk_rays_t<COUNT>(a.sc, w, P.o, P.d, false, stk, last ? 0 : n_alive >> kWalkRestShift, &wc);   // last: the rays under way are finished, none begun
         HgPending dep{};
         if (alive && in_flight && w.cur == kWalkOver) {   // this lane's ray has finished: the bounce, then its next ray
             bool specular;
@@ -574,7 +592,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
     }
     // the few paths left once the queue is empty: eight lanes to a ray in the wide tree (see k_camera_paths)
     while (__any(alive)) {
-        const Hit h = walk_wide(a.sc, alive, P.o, P.d, 1.7976931348623157e308, false, stk);
+        const Hit h = walk_wide_t<COUNT>(a.sc, alive, P.o, P.d, 1.7976931348623157e308, false, stk, &wc);
         HgPending dep{};
         if (alive) {
             ++traced;
@@ -586,6 +604,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, in
         if (KIND == 2) hg_deposit_wave(a.hg, dep);
     }
     count_wave_rays(counters, traced);
+    if (COUNT) count_wave_walk(counters, wc);
 }
 
 // Appends the staged photons of the batch in path order behind the `base`
@@ -829,10 +848,10 @@ TKD bool camera_after_ray(const CameraArgs& a, int x, int y, int pixel, int& bou
     if (!P.shadow) ++bounce;
     return go_on;
 }
-template <class STACK>
+template <bool COUNT, class STACK>
 TKD bool camera_turn(const CameraArgs& a, int x, int y, int pixel, int& bounce, CameraPath& P, CameraStepOut& so,
-                     STACK stk) {
-    const Hit h = trace_ray(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+                     STACK stk, WalkCount* wc) {
+    const Hit h = trace_ray_t<COUNT>(a.sc, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk, wc);
     return camera_after_ray(a, x, y, pixel, bounce, P, so, h);
 }
 
@@ -840,9 +859,11 @@ TKD bool camera_turn(const CameraArgs& a, int x, int y, int pixel, int& bounce, 
 // what its hit leads to, and the shadow ray of the light sample taken there,
 // one pixel per lane.  Camera rays are coherent and cheap and so are the shadow
 // rays that follow them; paths that go on are queued for the second stage.
+template <bool COUNT = false>
 __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int64_t n_slots, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kTraceBlock];
     LdsStack stk{&s_stack[threadIdx.x]};
+    WalkCount wc{0, 0};
     const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     bool alive = slot < n_slots;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
@@ -857,13 +878,13 @@ __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int6
         if (a.pt_mode)   // Pixel::filterWeightSum
             pt_footprint(a, pixel, P.flags, [&](int px) { atomicAdd(&a.planes[9 * a.n_pixels + px], 1.0f); });
         nrays = 1;
-        alive = camera_turn(a, x, y, pixel, bounce, P, so, stk);
+        alive = camera_turn<COUNT>(a, x, y, pixel, bounce, P, so, stk, &wc);
     }
     camera_emit_queries(a, counters, so, pixel);   // wave-wide appends: every lane takes part
     if (alive && P.shadow) {
         ++nrays;
         CameraStepOut none{};
-        alive = camera_turn(a, x, y, pixel, bounce, P, none, stk);
+        alive = camera_turn<COUNT>(a, x, y, pixel, bounce, P, none, stk, &wc);
     }
     const int at = queue_push(a.q, counters, alive, (P.flags & 1) != 0);
     if (alive) {
@@ -872,14 +893,17 @@ __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int6
         a.q.w[at] = make_float4(P.coef.x, P.coef.y, P.coef.z, __int_as_float(bounce));
     }
     count_wave_rays(counters, nrays);
+    if (COUNT) count_wave_walk(counters, wc);
 }
 
 // Second stage: the queued paths from their second segment on, organised like
 // k_photon_paths; path segments and shadow rays are in flight side by side.
 // spread: see lanes_in_use; otherwise the queue fills whole waves.
+template <bool COUNT = false>
 __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int spread, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
+    WalkCount wc{0, 0};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     if (!spread && (int64_t)blockIdx.x * 64 >= n) return;   // the waves before this one take the whole queue
     // spread: the paths at the front of the queue (from specular surfaces: the long ones) are dealt thinly
@@ -931,7 +955,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
             in_flight = true;
             ++nrays;
         }
-        walk_rays(a.sc, w, P.o, P.d, P.shadow, stk, last ? 0 : n_alive >> kWalkRestShift);   // last: the rays under way are finished, none begun
+        walk_rays_t<COUNT>(a.sc, w, P.o, P.d, P.shadow, stk, last ? 0 : n_alive >> kWalkRestShift, &wc);   // last: the rays under way are finished, none begun
         CameraStepOut so{};
         so.want_cq = so.want_gq = false;
         if (alive && in_flight && w.cur == kWalkOver) {   // this lane's ray has finished: what follows from it, then its next ray
@@ -950,7 +974,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
 #ifdef TK_CP_STAMPS
         ++st_wide_turns;
 #endif
-        const Hit h = walk_wide(a.sc, alive, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk);
+        const Hit h = walk_wide_t<COUNT>(a.sc, alive, P.o, P.d, P.shadow ? (double)kOneMinusEps : 1.7976931348623157e308, P.shadow, stk, &wc);
         CameraStepOut so{};
         so.want_cq = so.want_gq = false;
         if (alive) {
@@ -970,6 +994,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, in
     }
 #endif
     count_wave_rays(counters, nrays);
+    if (COUNT) count_wave_walk(counters, wc);
 }
 
 // The search radius of every query of one map, read again from its pixel (plane = the map's radius plane).
@@ -1037,7 +1062,64 @@ __global__ void k_unpack_dir(const uint16_t* dir, uint8_t* th, uint8_t* ph, int6
     ph[i] = (uint8_t)(dir[i] >> 8);
 }
 
+// ------------------------------------------------ photon exchange between ranks
+// One buffer of 32-bit words per rank: a header (per map: photons stored, light paths shot as 31 + 33 bits),
+// then per map the positions (3 words per photon), the powers (3) and the direction byte pairs (two photons
+// to a word), every array sized for the largest quota of any rank.  All ranks' buffers back to back are what
+// an all-gather delivers; k_exchange_unpack makes one map's arrays of them without the host reading a word.
+constexpr int kExchangeHeaderWords = 8;
+struct ExchangeLayout {
+    int64_t cap[2], pos[2], pow[2], dir[2], words;
+};
+__global__ void k_exchange_header(int32_t* buf, long long n0, long long shot0, long long n1, long long shot1) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    buf[0] = (int32_t)n0; buf[1] = (int32_t)(shot0 & 0x7fffffffll); buf[2] = (int32_t)(shot0 >> 31);
+    buf[3] = (int32_t)n1; buf[4] = (int32_t)(shot1 & 0x7fffffffll); buf[5] = (int32_t)(shot1 >> 31);
+    buf[6] = 0; buf[7] = 0;
+}
+__global__ void k_exchange_unpack(const int32_t* gathered, int64_t words, int world, int which, int64_t cap, int64_t o_pos,
+                                  int64_t o_pow, int64_t o_dir, float* pos, float* pow, uint16_t* dir, int64_t limit,
+                                  long long* totals_host) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i == 0) {
+        long long n = 0, shot = 0;
+        for (int q = 0; q < world; ++q) {
+            const int32_t* h = gathered + q * words + 3 * which;
+            n += h[0];
+            shot += (long long)h[1] + ((long long)h[2] << 31);
+        }
+        totals_host[2 * which] = n;
+        totals_host[2 * which + 1] = shot;
+    }
+    if (i >= (int64_t)world * cap) return;
+    const int r = (int)(i / cap);
+    const int64_t j = i - (int64_t)r * cap;
+    const int32_t* mine = gathered + r * words;
+    if (j >= mine[3 * which]) return;
+    int64_t at = j;                                   // photons of the ranks before this one come first
+    for (int q = 0; q < r; ++q) at += gathered[q * words + 3 * which];
+    if (at >= limit) return;                          // never beyond the map's arrays, whatever the headers say
+    const float* sp = reinterpret_cast<const float*>(mine + o_pos) + 3 * j;
+    const float* sw = reinterpret_cast<const float*>(mine + o_pow) + 3 * j;
+    pos[3 * at] = sp[0]; pos[3 * at + 1] = sp[1]; pos[3 * at + 2] = sp[2];
+    pow[3 * at] = sw[0]; pow[3 * at + 1] = sw[1]; pow[3 * at + 2] = sw[2];
+    dir[at] = reinterpret_cast<const uint16_t*>(mine + o_dir)[j];
+}
+
 // ----------------------------------------------------------------- host side
+static ExchangeLayout exchange_layout(const SppmState* s) {
+    ExchangeLayout L{};
+    int64_t off = kExchangeHeaderWords;
+    for (int w = 0; w < 2; ++w) {
+        const int64_t size = w == 0 ? s->prm.globalSize : s->prm.causticSize;
+        const int64_t cap = std::max<int64_t>(size / s->world + (size % s->world ? 1 : 0), 1);   // rank 0's quota: the largest
+        L.cap[w] = cap; L.pos[w] = off; L.pow[w] = off + 3 * cap; L.dir[w] = off + 6 * cap;
+        off += 6 * cap + (cap + 1) / 2;
+    }
+    L.words = off;
+    return L;
+}
+
 void destroy_sppm(tkhip_ctx* ctx) {
     SppmState* s = ctx->sppm;
     if (!s) return;
@@ -1053,6 +1135,9 @@ void destroy_sppm(tkhip_ctx* ctx) {
     s->planes.release();
     s->rows.release();
     s->preview.release();
+    if (s->ev_exchange) (void)hipEventDestroy(s->ev_exchange);
+    if (s->ev_preview) (void)hipEventDestroy(s->ev_preview);
+    if (s->h_exchange) (void)hipHostFree(s->h_exchange);
     for (DevBuf* b : {&s->hg_prm, &s->hg_bounds, &s->hg_count, &s->hg_start, &s->hg_cursor, &s->hg_items, &s->hg_phi, &s->hg_m})
         b->release();
     if (s->lane[0].stream) {
@@ -1069,13 +1154,14 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static int read_u64_counter(Lane& l, int at, int64_t* out) {
-    unsigned long long v = 0;
+// Rays, nodes fetched and primitives tested (C_RAYS, C_NODES, C_PRIMS: consecutive) of a lane's pass; cleared.
+static int read_walk_counters(Lane& l, int64_t out[3]) {
+    unsigned long long v[3] = {0, 0, 0};
     int32_t* c = l.counters.as<int32_t>();
-    TK_HIP(hipMemcpyAsync(&v, &c[at], 8, hipMemcpyDeviceToHost, l.stream));
+    TK_HIP(hipMemcpyAsync(v, &c[C_RAYS], 24, hipMemcpyDeviceToHost, l.stream));
     TK_HIP(hipStreamSynchronize(l.stream));
-    TK_HIP(hipMemsetAsync(&c[at], 0, 8, l.stream));
-    *out = (int64_t)v;
+    TK_HIP(hipMemsetAsync(&c[C_RAYS], 0, 24, l.stream));
+    for (int i = 0; i < 3; ++i) out[i] = (int64_t)v[i];
     return TKHIP_OK;
 }
 
@@ -1121,7 +1207,8 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     a.hoff = KIND == 0 ? 0 : s->caustic_hoff;
     a.world = s->world; a.rank = s->rank; a.seed = s->seed; a.rr = s->rr; a.slots = slots; a.depth = depth;
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
-    k_photon_first<KIND><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
+    if (s->counting) k_photon_first<KIND, true><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
+    else k_photon_first<KIND, false><<<divup(B, kTraceBlock), kTraceBlock, 0, stream>>>(a, B, counters);
     // Second-stage grid: enough waves for `photon_loads` path loads each of what the queue held last
     // time (the long paths need the refill to keep their waves full), at most what fits the GPU.  The
     // photon passes share the GPU with the camera pass: every wave slot a light-path kernel does not
@@ -1133,7 +1220,8 @@ static int photon_launch_batch(tkhip_ctx* ctx, int64_t stored, int64_t shot, int
     // A rank of several traces a share of the paths and leaves much of its GPU idle: there a fixed
     // share of the wave slots, over which the kernel spreads the queue thinly, is the faster shape.
     const int waves = s->world > 1 ? std::max(s->path_waves[KIND] * s->share[KIND] / 16, 64) : (int)std::min<int64_t>(want, s->path_waves[KIND]);
-    k_photon_paths<KIND><<<waves, kPathBlock, 0, stream>>>(a, counters);
+    if (s->counting) k_photon_paths<KIND, true><<<waves, kPathBlock, 0, stream>>>(a, counters);
+    else k_photon_paths<KIND, false><<<waves, kPathBlock, 0, stream>>>(a, counters);
     TK_LAUNCH_CHECK();
     TK_TRY(exclusive_scan_i32(stream, ln.prim_temp, ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(), (size_t)B));
     k_photon_scatter<<<divup(B, 256), 256, 0, stream>>>(ln.rec_count.as<int32_t>(), ln.rec_offset.as<int32_t>(),
@@ -1153,7 +1241,7 @@ static int photon_pass_begin(tkhip_ctx* ctx, int64_t* B_out) {
     Lane& ln = s->lane[KIND];
     *B_out = 0;
     if (s->quota[KIND] <= 0) return TKHIP_OK;
-    TK_HIP(hipMemsetAsync(&ln.counters.as<int32_t>()[C_RAYS], 0, 8, ln.stream));
+    TK_HIP(hipMemsetAsync(&ln.counters.as<int32_t>()[C_RAYS], 0, 24, ln.stream));
     return photon_launch_batch<KIND>(ctx, 0, 0, B_out);
 }
 
@@ -1245,13 +1333,15 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic, bo
     a.qcap = s->n_slots;
     a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)s->n_slots};
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
-    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, stream));
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 24, stream));
 #ifdef TK_CP_STAMPS
     TK_HIP(hipMemsetAsync(&counters[224], 0, 64, stream));
 #endif
-    k_camera_first<<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
+    if (s->counting) k_camera_first<true><<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
+    else k_camera_first<false><<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
     const int waves = s->world > 1 ? std::max(s->path_waves[2] * s->share[2] / 16, 64) : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
-    k_camera_paths<<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
+    if (s->counting) k_camera_paths<true><<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
+    else k_camera_paths<false><<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
     TK_LAUNCH_CHECK();
     TK_HIP(hipMemcpyAsync(ln.h_counters, counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
     return TKHIP_OK;
@@ -1410,10 +1500,11 @@ static int gather_both(tkhip_ctx* ctx, TkIterStats* st) {
 
 static int collect_rays(tkhip_ctx* ctx, int lane, TkIterStats* st) {
     if (!st) return TKHIP_OK;
-    int64_t rays = 0;
-    TK_TRY(read_u64_counter(ctx->sppm->lane[lane], C_RAYS, &rays));
-    st->rays += rays;
-    if (lane == 2) st->rays_camera += rays;
+    int64_t v[3] = {0, 0, 0};
+    TK_TRY(read_walk_counters(ctx->sppm->lane[lane], v));
+    st->rays += v[0];
+    if (lane == 2) { st->rays_camera += v[0]; st->node_visits_camera += v[1]; st->prim_tests_camera += v[2]; }
+    else { st->node_visits_light += v[1]; st->prim_tests_light += v[2]; }
     return TKHIP_OK;
 }
 
@@ -1428,6 +1519,9 @@ static int maybe_preview(tkhip_ctx* ctx, int iter, bool force) {
                                                                s->preview.as<uint32_t>());
     TK_LAUNCH_CHECK();
     s->preview_iter = iter;
+    // the next camera pass (lane 2) adds into the planes this kernel reads: it waits for the preview by an event
+    TK_HIP(hipEventRecord(s->ev_preview, ctx->stream));
+    TK_HIP(hipStreamWaitEvent(s->lane[2].stream, s->ev_preview, 0));
     return TKHIP_OK;
 }
 
@@ -1457,7 +1551,7 @@ static int sppm_begin_launches(tkhip_ctx* ctx, SppmState* s, const std::vector<i
         ca.sc = ctx->scene; ca.cam = ctx->cam;
         k_photon_paths<0><<<s->path_waves[0], kPathBlock, 0, s->lane[0].stream>>>(pa, s->lane[0].counters.as<int32_t>());
         k_photon_paths<1><<<s->path_waves[1], kPathBlock, 0, s->lane[1].stream>>>(pa, s->lane[1].counters.as<int32_t>());
-        k_camera_paths<<<s->path_waves[2], kPathBlock, 0, s->lane[2].stream>>>(ca, 1, s->lane[2].counters.as<int32_t>());
+        k_camera_paths<false><<<s->path_waves[2], kPathBlock, 0, s->lane[2].stream>>>(ca, 1, s->lane[2].counters.as<int32_t>());
         TK_LAUNCH_CHECK();
         // likewise the scan and the sort of the library the passes use (their first call is slow)
         for (int w = 0; w < 2; ++w) {
@@ -1633,6 +1727,15 @@ int sppm_local_photons(tkhip_ctx* ctx, int which, const void** pos, const void**
     *shot = s->last_shot[which];
     return TKHIP_OK;
 }
+// Camera paths begun ahead (tkhip_sppm_camera_pass_ahead, tkhip_sppm_camera_begin) add direct light into the
+// pixel planes on their own stream: whoever reads the planes on another stream waits for them first.  The
+// pass stays "in flight" for the iteration that picks it up.
+int sppm_wait_camera_lane(tkhip_ctx* ctx) {
+    SppmState* s = ctx->sppm;
+    if (s && s->camera_in_flight >= 0 && s->lane[2].stream) TK_HIP(hipStreamSynchronize(s->lane[2].stream));
+    return TKHIP_OK;
+}
+float* sppm_planes_device(tkhip_ctx* ctx) { return ctx->sppm ? ctx->sppm->planes.as<float>() : nullptr; }
 }  // namespace tkd
 
 #define TK_CTX_SPPM(ctx, fn)                                                             \
@@ -1673,13 +1776,19 @@ int tkhip_sppm_begin(tkhip_ctx* ctx, const TkSppmParam* param, int max_depth, fl
         std::memset(l.h_counters, 0, kCounterBytes);
         if (hipMemsetAsync(l.counters.p, 0, kCounterBytes, l.stream) != hipSuccess) { set_error("tkhip_sppm_begin: memset failed"); rc = TKHIP_E_HIP; break; }
     }
+    if (!rc && (hipEventCreateWithFlags(&s->ev_exchange, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_preview, hipEventDisableTiming) != hipSuccess ||
+                hipHostMalloc(reinterpret_cast<void**>(&s->h_exchange), 4 * sizeof(long long), hipHostMallocDefault) != hipSuccess)) {
+        set_error("tkhip_sppm_begin: exchange set-up failed");
+        rc = TKHIP_E_HIP;
+    }
     if (!rc) {
         hipDeviceProp_t prop{};
         int per_cu[3] = {0, 0, 0};
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k_photon_paths<0>, kPathBlock, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k_photon_paths<1>, kPathBlock, 0) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[2], k_camera_paths, kPathBlock, 0) != hipSuccess) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[2], k_camera_paths<false>, kPathBlock, 0) != hipSuccess) {
             set_error("tkhip_sppm_begin: occupancy query failed");
             rc = TKHIP_E_HIP;
         } else {
@@ -1818,10 +1927,92 @@ int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, cons
     return TKHIP_OK;
 }
 
+int tkhip_sppm_exchange_words(tkhip_ctx* ctx, int64_t* words_per_rank) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_exchange_words");
+    TK_REQUIRE(words_per_rank, TKHIP_E_ARG, "tkhip_sppm_exchange_words: null argument");
+    *words_per_rank = exchange_layout(ctx->sppm).words;
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_export_exchange(tkhip_ctx* ctx, int32_t* device_buf, void* stream_handle) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_export_exchange");
+    TK_REQUIRE(device_buf, TKHIP_E_ARG, "tkhip_sppm_export_exchange: null buffer");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(!s->photon_begun, TKHIP_E_STATE, "tkhip_sppm_export_exchange: finish the photon pass first (tkhip_sppm_photon_pass)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_handle);
+    const ExchangeLayout L = exchange_layout(s);
+    // the photon pass has waited for its lanes: the rank's arrays are complete and can be read on any stream
+    k_exchange_header<<<1, 64, 0, stream>>>(device_buf, (long long)s->n_loc[0], (long long)s->last_shot[0], (long long)s->n_loc[1],
+                                            (long long)s->last_shot[1]);
+    TK_LAUNCH_CHECK();
+    for (int w = 0; w < 2; ++w) {
+        const size_t n = (size_t)s->n_loc[w];
+        if (n == 0) continue;
+        TK_HIP(hipMemcpyAsync(device_buf + L.pos[w], s->loc_pos[w].p, n * 12, hipMemcpyDeviceToDevice, stream));
+        TK_HIP(hipMemcpyAsync(device_buf + L.pow[w], s->loc_pow[w].p, n * 12, hipMemcpyDeviceToDevice, stream));
+        TK_HIP(hipMemcpyAsync(device_buf + L.dir[w], s->loc_dir[w].p, n * 2, hipMemcpyDeviceToDevice, stream));
+    }
+    // the next photon pass overwrites the rank's arrays: its lanes wait for these copies, the host does not
+    TK_HIP(hipEventRecord(s->ev_exchange, stream));
+    TK_HIP(hipStreamWaitEvent(s->lane[0].stream, s->ev_exchange, 0));
+    TK_HIP(hipStreamWaitEvent(s->lane[1].stream, s->ev_exchange, 0));
+    return TKHIP_OK;
+}
+
+int tkhip_sppm_import_exchange(tkhip_ctx* ctx, const int32_t* device_gathered, void* stream_handle) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_import_exchange");
+    TK_REQUIRE(device_gathered, TKHIP_E_ARG, "tkhip_sppm_import_exchange: null buffer");
+    SppmState* s = ctx->sppm;
+    TK_REQUIRE(s->world > 1, TKHIP_E_STATE, "tkhip_sppm_import_exchange: a single rank installs its photons in tkhip_sppm_photon_pass");
+    hipStream_t stream = static_cast<hipStream_t>(stream_handle);
+    const ExchangeLayout L = exchange_layout(s);
+    TK_HIP(hipEventRecord(s->ev_exchange, stream));     // whatever filled the buffer on the caller's stream (the all-gather)
+    for (int w = 0; w < 2; ++w) {
+        tkhip_map* m = s->map[w];
+        const int64_t size = w == 0 ? s->prm.globalSize : s->prm.causticSize;
+        s->exchange_expected[w] = size;
+        s->h_exchange[2 * w] = -1;
+        m->n = size;          // every rank fills its quota as a rule; tkhip_sppm_build_maps checks the sum the device found
+        m->built = false;
+        if (w == 1) s->stored_c = size;
+        if (size == 0) { s->h_exchange[2 * w] = 0; s->h_exchange[2 * w + 1] = 0; continue; }
+        TK_HIP(hipStreamWaitEvent(m->stream, s->ev_exchange, 0));
+        k_exchange_unpack<<<divup((int64_t)s->world * L.cap[w], 256), 256, 0, m->stream>>>(
+            device_gathered, L.words, s->world, w, L.cap[w], L.pos[w], L.pow[w], L.dir[w], m->in_pos.as<float>(), m->in_pow.as<float>(),
+            m->in_dir.as<uint16_t>(), m->cap, s->h_exchange);
+        TK_LAUNCH_CHECK();
+    }
+    s->exchange_pending = true;
+    return TKHIP_OK;
+}
+
+// After the builds that follow an import (their streams have been waited for): the totals the device summed
+// from the ranks' headers.  A rank that could not fill its quota (a scene that takes no caustic photons) makes
+// a map smaller than assumed: its tree is built again over the photons there are.
+static int exchange_settle(tkhip_ctx* ctx) {
+    SppmState* s = ctx->sppm;
+    s->exchange_pending = false;
+    for (int w = 0; w < 2; ++w) {
+        tkhip_map* m = s->map[w];
+        TK_HIP(hipStreamSynchronize(m->stream));
+        const long long n = s->h_exchange[2 * w], shot = s->h_exchange[2 * w + 1];
+        TK_REQUIRE(n >= 0 && n <= s->exchange_expected[w], TKHIP_E_STATE, "photon exchange: the ranks report %lld photons for a map of %lld",
+                   n, (long long)s->exchange_expected[w]);
+        s->shoot[w] += shot;
+        if (n == s->exchange_expected[w]) continue;
+        m->n = n;
+        if (w == 1) s->stored_c = n;
+        if (w == 0 || n > 0) TK_TRY(map_build(m));
+        TK_HIP(hipStreamSynchronize(m->stream));
+    }
+    return TKHIP_OK;
+}
+
 int tkhip_sppm_build_maps(tkhip_ctx* ctx, TkIterStats* st) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_build_maps");
     double ms = 0;
     TK_TRY(build_both(ctx, &ms));
+    if (ctx->sppm->exchange_pending) TK_TRY(exchange_settle(ctx));
     if (st) st->ms_build += (float)ms;
     return TKHIP_OK;
 }
@@ -1830,6 +2021,12 @@ int tkhip_sppm_set_tree(tkhip_ctx* ctx, int mode) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_set_tree");
     TK_TRY(tkhip_map_set_tree(ctx->sppm->map[0], mode));
     return tkhip_map_set_tree(ctx->sppm->map[1], mode);
+}
+
+int tkhip_sppm_set_counting(tkhip_ctx* ctx, int on) {
+    TK_CTX_SPPM(ctx, "tkhip_sppm_set_counting");
+    ctx->sppm->counting = on != 0;
+    return TKHIP_OK;
 }
 
 int tkhip_sppm_set_jitter(tkhip_ctx* ctx, int jitter) {
@@ -2074,6 +2271,7 @@ int tkhip_sppm_export_planes(tkhip_ctx* ctx, float* device_dst) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_export_planes");
     TK_REQUIRE(device_dst, TKHIP_E_ARG, "tkhip_sppm_export_planes: null buffer");
     SppmState* s = ctx->sppm;
+    TK_TRY(sppm_wait_camera_lane(ctx));   // a camera pass begun ahead is still adding direct light
     TK_HIP(hipMemcpyAsync(device_dst, s->planes.p, (size_t)s->n_pixels * 52, hipMemcpyDeviceToDevice, ctx->stream));
     TK_HIP(hipStreamSynchronize(ctx->stream));
     return TKHIP_OK;
@@ -2083,6 +2281,9 @@ int tkhip_sppm_import_planes(tkhip_ctx* ctx, const float* device_src) {
     TK_CTX_SPPM(ctx, "tkhip_sppm_import_planes");
     TK_REQUIRE(device_src, TKHIP_E_ARG, "tkhip_sppm_import_planes: null buffer");
     SppmState* s = ctx->sppm;
+    // the direct light a camera pass begun ahead has added since the planes were exported would be overwritten
+    TK_REQUIRE(s->camera_in_flight < 0, TKHIP_E_STATE,
+               "tkhip_sppm_import_planes: the camera paths of iteration %d are in flight; run that iteration first", s->camera_in_flight);
     TK_HIP(hipMemcpyAsync(s->planes.p, device_src, (size_t)s->n_pixels * 52, hipMemcpyDeviceToDevice, ctx->stream));
     TK_HIP(hipStreamSynchronize(ctx->stream));
     return TKHIP_OK;
@@ -2209,7 +2410,7 @@ int tkhip_hsppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     Lane& ln = s->lane[0];
     const int64_t per_it = s->prm.globalSize;
     int32_t* counters = ln.counters.as<int32_t>();
-    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 8, ln.stream));
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 24, ln.stream));
     for (int64_t done = 0; done < per_it;) {
         const int64_t B = std::min<int64_t>(per_it - done, (int64_t)1 << 22);
         PhotonArgs a{};

@@ -259,6 +259,8 @@ int tkhip_set_scene(tkhip_ctx* ctx, const TkObject* objects, int n_objects, cons
         TK_TRY(build_bvh_device(s, ctx->prim_temp, d_tris.as<TkTriangle>(), n_tris, d_sph.as<TkSphere>(), n_spheres, kMaxLeaf,
                                 kStackDepth, ctx->b_nodes, ctx->b_tri_isect, &n_nodes, &depth, bmin, bmax));
         lap("tree built on the device");
+        // the same bound as for the host-built tree: a ray's stack holds one entry per level it has passed
+        TK_REQUIRE(depth < kStackDepth - 1, TKHIP_E_LIMIT, "scene BVH depth %d (built on the device) exceeds the traversal stack", depth);
     } else {
         HostBvh bvh;
         build_bvh(tris, n_tris, spheres, n_spheres, kMaxLeaf, kStackDepth, &bvh);

@@ -198,8 +198,9 @@ TKD void prim_test(const DScene& sc, const TriIsect& T, F3 o, F3 d, Hit* h) {
 
 // A leaf holds at most kMaxLeaf primitives; the records of the first two are
 // fetched together (independent loads in flight) before either is tested.
-TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h) {
+TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int* prims_tested = nullptr) {
     const int first = enc >> 3, count = (enc & 7) + 1;
+    if (prims_tested) *prims_tested += count;
     const TriIsect T0 = sc.tri_isect[first];
     const TriIsect T1 = sc.tri_isect[first + (count > 1 ? 1 : 0)];
     prim_test(sc, T0, o, d, h);
@@ -232,6 +233,11 @@ TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h) {
 // and the slow rays simply continue in the next call.
 constexpr int kWalkOver = 0x7fffffff;   // RayWalk::cur of a lane whose ray has finished (or that has none)
 constexpr int kLeafShare = 8;           // sixteenths of the rays in flight that must hold a leaf before leaves are tested
+// What a counting instance of a walk adds up per lane: nodes of the tree fetched (a node holds the boxes of
+// both children; a node of the eight-children tree counts as four, by its size) and primitives tested.
+struct WalkCount {
+    int nodes, prims;
+};
 struct RayWalk {
     int cur;        // node to visit next, ~leaf to test next, or kWalkOver
     int sp;
@@ -254,8 +260,8 @@ TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
 // Advances the rays in flight (lanes with cur != kWalkOver) until at most
 // `rest` of them are unfinished.  Called by all the lanes that take part, in
 // step; the votes below count those lanes only.
-template <class STACK>
-TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest) {
+template <bool COUNT, class STACK>
+TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest, WalkCount* wc) {
     while (true) {
         const int busy = __popcll(__ballot(w.cur != kWalkOver));
         while (true) {
@@ -264,6 +270,7 @@ TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK
             if (n_inner == 0 || (busy - n_inner) * 16 >= busy * kLeafShare) break;
             if (!inner) continue;
             const BvhNode nd = sc.nodes[w.cur];
+            if (COUNT) ++wc->nodes;
             float tl, tr;
             bool hl, hr;
             if (__builtin_expect(w.zero_dir, 0)) {
@@ -290,7 +297,7 @@ TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK
             }
         }
         if (w.cur < 0) {
-            leaf_test(sc, ~w.cur, o, d, &w.h);
+            leaf_test(sc, ~w.cur, o, d, &w.h, COUNT ? &wc->prims : nullptr);
             w.tcull = w.h.t >= 3.0e38 ? 3.4e38f : (float)w.h.t * 1.0000002f;
             if ((any_hit && w.h.prim >= 0) || w.sp == 0) w.cur = kWalkOver;
             else { --w.sp; w.cur = st.pop(w.sp); }
@@ -299,11 +306,19 @@ TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK
     }
 }
 template <class STACK>
-TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK st) {
+TKD void walk_rays(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest) {
+    walk_rays_t<false>(sc, w, o, d, any_hit, st, rest, nullptr);
+}
+template <bool COUNT, class STACK>
+TKD Hit trace_ray_t(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK st, WalkCount* wc) {
     RayWalk w;
     walk_begin(w, sc, d, tmax);
-    walk_rays(sc, w, o, d, any_hit, st, 0);
+    walk_rays_t<COUNT>(sc, w, o, d, any_hit, st, 0, wc);
     return w.h;
+}
+template <class STACK>
+TKD Hit trace_ray(const DScene& sc, F3 o, F3 d, double tmax, bool any_hit, STACK st) {
+    return trace_ray_t<false>(sc, o, d, tmax, any_hit, st, nullptr);
 }
 
 // ---------------------------------------------------------------- wide walk
@@ -324,8 +339,9 @@ TKD uint32_t wide_order_key(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-template <int STRIDE>
-TKD Hit walk_wide(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_in, bool any_hit_in, LdsStackT<STRIDE> st) {
+template <bool COUNT, int STRIDE>
+TKD Hit walk_wide_t(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_in, bool any_hit_in, LdsStackT<STRIDE> st,
+                    WalkCount* wc) {
     const int lane = (int)(threadIdx.x & 63);
     const int sub = lane & 7, grp = lane >> 3, lane0 = grp << 3;
     int* const col = st.base - lane + lane0;         // row 0 of the group's first column
@@ -355,13 +371,14 @@ TKD Hit walk_wide(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_in,
         while (__any(active)) {
             if (active) {
                 const WideChild ch = sc.wide[cur].c[sub];
+                if (COUNT && sub == 0) wc->nodes += 4;     // counted with the lanes that serve the ray, not with its owner
                 float tn = 0.f;
                 bool hit = false;
                 if (ch.ref != kWideEmpty)
                     hit = zero_dir ? box_hit_zero_dir(ch.lo, ch.hi, o, d, dinv, tcull, &tn) : box_hit(ch.lo, ch.hi, o, dinv, tcull, &tn);
                 Hit mine = best;
                 mine.prim = -1;
-                if (hit && ch.ref < 0) leaf_test(sc, ~ch.ref, o, d, &mine);
+                if (hit && ch.ref < 0) leaf_test(sc, ~ch.ref, o, d, &mine, COUNT ? &wc->prims : nullptr);
                 // hits of this visit nearer than the best so far, lane by lane
                 unsigned fm = (unsigned)(__ballot(mine.prim >= 0) >> lane0) & 0xffu;
                 while (fm) {
@@ -412,6 +429,10 @@ TKD Hit walk_wide(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_in,
         if (mine_now) { result.t = t; result.u = u; result.v = v; result.prim = prim; }
     }
     return result;
+}
+template <int STRIDE>
+TKD Hit walk_wide(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_in, bool any_hit_in, LdsStackT<STRIDE> st) {
+    return walk_wide_t<false>(sc, want, o_in, d_in, tmax_in, any_hit_in, st, nullptr);
 }
 
 // Fills the surface record of a hit: Triangle::intersect :39-48 or

@@ -253,5 +253,9 @@ void destroy_sppm(tkhip_ctx* ctx);
 // 3 floats, 3 floats, 2 bytes per photon) and the light paths it shot for them.
 int sppm_local_photons(tkhip_ctx* ctx, int which, const void** pos, const void** pow, const void** dir, int64_t* n,
                        int64_t* shot);
+// Waits for camera paths that were begun ahead and are still adding direct light to the pixel planes (they stay
+// "in flight" for the iteration that picks them up); the planes of the render on the context's GPU.
+int sppm_wait_camera_lane(tkhip_ctx* ctx);
+float* sppm_planes_device(tkhip_ctx* ctx);
 
 }  // namespace tkd

@@ -315,24 +315,30 @@ int tkhip_group_sppm_merge(tkhip_group* g) {
     TK_REQUIRE(g && g->rendering, TKHIP_E_STATE, "tkhip_group_sppm_merge: call tkhip_group_sppm_begin first");
     if (g->n == 1) return TKHIP_OK;
     const size_t bytes = (size_t)g->width * (size_t)g->height * 13 * sizeof(float);
+    // Every rank but rank 0 snapshots its planes (camera paths begun ahead with begin_next 2 are waited for:
+    // the snapshot then holds their direct light, as the rank's own planes do).  Rank 0 only waits.
     TK_TRY(g->run([=](int r) {
         TK_HIP(hipSetDevice(g->device[(size_t)r]));
+        if (r == 0) return sppm_wait_camera_lane(g->ctx[0]);
         TK_TRY(g->bufs[(size_t)r].planes.ensure(bytes));
         return tkhip_sppm_export_planes(g->ctx[(size_t)r], g->bufs[(size_t)r].planes.as<float>());
     }));
+    // The other ranks' rows go straight into rank 0's planes; its own rows are not rewritten, so whatever its
+    // camera paths begun ahead have added to them stays, and the render goes on from the merged state.
     tkhip_ctx* c0 = g->ctx[0];
     tkhip_group::Bufs& B0 = g->bufs[0];
     TK_HIP(hipSetDevice(g->device[0]));
     TK_TRY(B0.incoming.ensure(bytes));
+    float* live = sppm_planes_device(c0);
+    TK_REQUIRE(live, TKHIP_E_STATE, "tkhip_group_sppm_merge: rank 0 holds no render");
     const int64_t words = (int64_t)(bytes / 4);
     for (int q = 1; q < g->n; ++q) {
         TK_HIP(hipMemcpyPeerAsync(B0.incoming.p, g->device[0], g->bufs[(size_t)q].planes.p, g->device[(size_t)q], bytes, c0->stream));
-        k_merge_rows<<<divup(words, 256), 256, 0, c0->stream>>>(B0.planes.as<float>(), B0.incoming.as<float>(), g->width, g->height,
-                                                                g->n, q);
+        k_merge_rows<<<divup(words, 256), 256, 0, c0->stream>>>(live, B0.incoming.as<float>(), g->width, g->height, g->n, q);
         TK_LAUNCH_CHECK();
     }
     TK_HIP(hipStreamSynchronize(c0->stream));
-    return tkhip_sppm_import_planes(c0, B0.planes.as<float>());
+    return TKHIP_OK;
 }
 
 }  // extern "C"

@@ -87,6 +87,24 @@ class HipBackend:
                                                             direction.data_ptr(), n, shot_total),
               "tkhip_sppm_set_map_photons")
 
+    # the exchange through one buffer per rank, laid out and unpacked by the library on the device
+    def exchange_words(self):
+        w = C.c_int64()
+        check(self.lib, self.lib.tkhip_sppm_exchange_words(self.h, C.byref(w)), "tkhip_sppm_exchange_words")
+        return w.value
+
+    def export_exchange(self, buf):
+        """This rank's header and photons of both maps into `buf` (int32, exchange_words() long) on torch's current
+        stream; nothing is waited for."""
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        check(self.lib, self.lib.tkhip_sppm_export_exchange(self.h, buf.data_ptr(), stream), "tkhip_sppm_export_exchange")
+
+    def import_exchange(self, gathered):
+        """All ranks' buffers back to back (as the all-gather leaves them on torch's current stream) become the two
+        maps; the counts stay on the device (build_maps settles them)."""
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        check(self.lib, self.lib.tkhip_sppm_import_exchange(self.h, gathered.data_ptr(), stream), "tkhip_sppm_import_exchange")
+
     def build_maps(self, stats=None):
         self.tracer.build_maps(stats)
 
@@ -133,6 +151,18 @@ def _all_gather(t, world):
     return parts
 
 
+def _all_gather_flat(t, world):
+    """All ranks' equally long 1-D tensors back to back in one tensor on t's device."""
+    if _on_host(t):
+        h = t.cpu()
+        out = torch.empty((world * h.numel(),), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h)
+        return out.to(t.device)
+    out = torch.empty((world * t.numel(),), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
 def _exchange_layout(caps):
     """Word offsets inside one rank's exchange buffer (int32 words): 8 header words, then per map the
     positions (3 words per photon), the powers (3) and the direction pairs (2 bytes per photon, padded to
@@ -152,6 +182,19 @@ def exchange_photons(backend, world):
     writes its photons straight into that buffer.  Returns [(n_total, shot_total)] per map."""
     if world == 1:
         return [None, None]   # a single rank installs its own photons at the end of its photon pass
+    if hasattr(backend, "export_exchange"):
+        # The library lays the buffer out, fills it and unpacks the gathered buffers on the device: between the
+        # photon pass and the tree builds the host reads nothing and waits for nothing (with RCCL; gloo, the
+        # rehearsal backend, moves the buffers through host memory).  Counts and shot totals are settled by
+        # build_maps, so there are no totals to return here.
+        send = getattr(backend, "_exchange_send", None)
+        if send is None:
+            send = backend._exchange_send = torch.empty((backend.exchange_words(),), dtype=torch.int32, device=backend.dev)
+        backend.export_exchange(send)
+        gathered = _all_gather_flat(send, world)
+        backend.import_exchange(gathered)
+        backend._exchange_gathered = gathered      # stays alive until the next exchange replaces it
+        return [None, None]
     direct = hasattr(backend, "export_local_into")
     if direct:
         caps = [max(q, 1) for q in backend.max_quota]

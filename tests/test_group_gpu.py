@@ -66,6 +66,29 @@ def test_group_iterations_match_the_sharded_oracle(world, begin_next):
     grp.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_merge_with_the_next_camera_paths_in_flight(world):
+    """begin_next 2 leaves the camera paths of the next iteration adding direct light to the pixels when the call
+    returns.  A merge at that moment (a mid-render save) waits for them, moves only the other ranks' rows into
+    rank 0's pixels and loses nothing: the iterations that follow end in the sharded oracle's pixel state."""
+    scene = Scene.load(asset_scene("cornell_sphere.scene"))
+    W, GS, CS = 64, 8000, 1000
+    prm = scene.sppm_param(globalSize=GS, causticSize=CS, numRecurse=4)
+    grp = SppmGroup(scene, [0] * world, prm, scene.tracer.max_depth, scene.tracer.russian_roulette, W, W)
+    grp.iteration(0, begin_next=2)
+    mid = grp.pixels()                       # merges with iteration 1's camera paths in flight
+    one = _oracle_sharded(scene, prm, W, world, 1)
+    assert np.array_equal(mid[:, 9:13], one[:, 9:13])          # photon counts and radii: after one iteration
+    np.testing.assert_allclose(mid[:, 3:9], one[:, 3:9], rtol=1e-5, atol=1e-10)
+    grp.iteration(1, begin_next=2)
+    grp.merge()
+    img = grp.resolve(4)
+    assert img.mean() > 10
+    grp.iteration(2)
+    _assert_pixels_equal(grp.pixels(), _oracle_sharded(scene, prm, W, world, 3))
+    grp.close()
+
+
 def test_group_of_one_is_the_single_gpu_render():
     scene = Scene.load(asset_scene("cornell_box.scene"))
     prm = scene.sppm_param(globalSize=5000, causticSize=0, numRecurse=4)

@@ -46,7 +46,7 @@ def test_abi_struct_sizes_match_the_header():
     assert C.sizeof(_abi.TkTriangle) == 36 and C.sizeof(_abi.TkSphere) == 16
     assert C.sizeof(_abi.TkMaterial) == 36 and C.sizeof(_abi.TkLight) == 20 and C.sizeof(_abi.TkObject) == 20
     assert C.sizeof(_abi.TkSppmParam) == 24 and C.sizeof(_abi.TkSPPMPixel) == 52
-    assert C.sizeof(_abi.TkIterStats) == 13 * 8 + 6 * 4 + 8
+    assert C.sizeof(_abi.TkIterStats) == 13 * 8 + 6 * 4 + 8 + 4 * 8
 
 
 def test_argument_errors_without_touching_the_gpu():

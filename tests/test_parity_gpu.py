@@ -595,9 +595,9 @@ def test_rank_sharding_on_one_gpu(world):
 
 
 def test_photon_exchange_buffer_on_one_gpu(monkeypatch):
-    """The one-collective photon exchange of the multi-rank driver (flat buffer, photons exported straight into
-    it) against the exchange by hand, for a world of 3 whose quotas leave a remainder; the all-gather is played
-    by handing every rank's buffer to rank 0."""
+    """The one-collective photon exchange of the multi-rank driver (one buffer per rank, laid out, filled and
+    unpacked by the library on the device) against the exchange by hand, for a world of 3 whose quotas leave a
+    remainder; the all-gather is played by handing every rank's buffer to rank 0."""
     import torch
     from pathtracer_amd import distributed as D
     world = 3
@@ -617,24 +617,75 @@ def test_photon_exchange_buffer_on_one_gpu(monkeypatch):
     sent = {}
     for r, be in enumerate(bes):
         def record(t, w, r=r):
+            torch.cuda.synchronize()
             sent[r] = t.clone()
             raise Recorded()
-        monkeypatch.setattr(D, "_all_gather", record)
+        monkeypatch.setattr(D, "_all_gather_flat", record)
         with pytest.raises(Recorded):
             D.exchange_photons(be, world)
     assert len({int(t.numel()) for t in sent.values()}) == 1        # equal sizes: one plain all-gather
-    monkeypatch.setattr(D, "_all_gather", lambda t, w: [sent[r] for r in range(w)])
-    totals = D.exchange_photons(bes[0], world)
+    assert int(sent[0].numel()) == bes[0].exchange_words()
+    monkeypatch.setattr(D, "_all_gather_flat", lambda t, w: torch.cat([sent[r] for r in range(w)]))
+    before = bes[0].tracer.counters()
+    D.exchange_photons(bes[0], world)
+    bes[0].build_maps()               # settles the counts and shot totals the device summed
+    after = bes[0].tracer.counters()
     for which, size in ((0, GS), (1, CS)):
         (pos, power, direction), shot = hand[which]
-        assert totals[which] == (size, shot)
+        assert after[which] - before[which] == shot
         gp, gw, th, ph = bes[0].tracer.photons(which)
+        assert len(gp) == size
         assert np.array_equal(gp, pos) and np.array_equal(gw, power)
         assert np.array_equal(th.astype(np.uint16) | (ph.astype(np.uint16) << 8), direction.view(np.uint16))
-    bes[0].build_maps()
     bes[0].camera_pass(0)
     assert bes[0].resolve().mean() > 1
     for be in bes:
+        be.close()
+
+
+def test_photon_exchange_with_a_quota_no_rank_can_fill(monkeypatch):
+    """cornell_box holds nothing specular: no rank stores a caustic photon (its pass gives up at the emission
+    cap), so the map comes out smaller than the sum of the quotas the host assumed when it enqueued the builds.
+    The settled render equals the one whose exchange is made by hand with the true counts."""
+    import torch
+    from pathtracer_amd import distributed as D
+    world = 2
+    scene = Scene.load(asset_scene("cornell_box.scene"))
+    W, GS, CS = 32, 4000, 40
+    prm = scene.sppm_param(globalSize=GS, causticSize=CS, numRecurse=4)
+    dev = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, world, 0) for r in range(world)]
+    hand = [D.HipBackend(scene, prm, 20, 0.8, 0x5EED, W, W, r, world, 0) for r in range(world)]
+    for it in range(2):
+        for be in dev + hand:
+            be.photon_pass(it)
+        sent = {}
+        class Recorded(Exception):
+            pass
+        for r, be in enumerate(dev):
+            def record(t, w, r=r):
+                torch.cuda.synchronize()
+                sent[r] = t.clone()
+                raise Recorded()
+            monkeypatch.setattr(D, "_all_gather_flat", record)
+            with pytest.raises(Recorded):
+                D.exchange_photons(be, world)
+        monkeypatch.setattr(D, "_all_gather_flat", lambda t, w: torch.cat([sent[r] for r in range(w)]))
+        for be in dev:
+            D.exchange_photons(be, world)
+        for which in (0, 1):
+            parts = [be.export_local(which) for be in hand]
+            if which == 1:
+                assert [p[3] for p in parts] == [0, 0]
+            cat = [torch.cat([p[i][:p[3]] for p in parts]).contiguous() for i in range(3)]
+            for be in hand:
+                be.set_map(which, cat[0], cat[1], cat[2], sum(p[3] for p in parts), sum(p[4] for p in parts))
+        for be in dev + hand:
+            be.build_maps()
+            be.camera_pass(it)
+    for a, b in zip(dev, hand):
+        assert a.tracer.counters() == b.tracer.counters()
+        assert np.array_equal(a.export_planes().cpu().numpy(), b.export_planes().cpu().numpy())
+    for be in dev + hand:
         be.close()
 
 

@@ -38,17 +38,29 @@ def test_static_gather_matches_the_allocating_entry_point():
     m = PhotonMap(ctx, len(pos), k)
     m.store(pos, power, th, ph)
     m.build()
+    import torch
     for nq in (30000, 7001):        # the second call is smaller: stale scratch of the first must not show
         q = make_queries(rng, nq)
         fl, fo, r2, idx = m.gather(*q, mode=0)
         sfl, sfo, sr2, sidx = _static_gather(m, *q)
+        # and it allocates nothing: the device's free memory is the same before and after a call whose inputs
+        # and outputs exist already (the first call above has loaded every kernel it launches)
+        dev = [torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda() for a in q]
+        outs = [torch.zeros((nq, 3), device="cuda"), torch.zeros((nq,), dtype=torch.int32, device="cuda"),
+                torch.zeros((nq,), device="cuda")]
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        rc = m.lib.tkhip_map_gather_static(m.h, nq, *[d.data_ptr() for d in dev], *[o.data_ptr() for o in outs], None)
+        free_after = torch.cuda.mem_get_info()[0]
+        _abi.check(m.lib, rc, "tkhip_map_gather_static")
+        assert free_after == free_before
+        assert (outs[1].cpu().numpy() == fo).all()
         assert (sfo == fo).all()
         assert bits_equal(sr2, r2)
         assert (sidx == idx).all()
         np.testing.assert_allclose(sfl, fl, rtol=1e-5, atol=1e-12)
         assert (fo >= k).any() and (fo < k).any()       # both gather kernels took part
     # beyond the stated maximum: a clear error, nothing run
-    import torch
     z = torch.zeros(8, device="cuda")
     rc = m.lib.tkhip_map_gather_static(m.h, 65537, *[z.data_ptr()] * 5, z.data_ptr(), z.data_ptr(), z.data_ptr(), None)
     assert rc == -5 and b"at most" in m.lib.tkhip_last_error()
