@@ -28,6 +28,12 @@ trap 'rm -rf "$S"' EXIT
 cp -r "$REF/src/." "$S/"
 chmod -R u+w "$S"
 sed -i 's/^\tstatic inline \(f32\|f64\) Math::/\tinline \1 Math::/' "$S/TkMath.h"
+# Second edit, for the second prober only (ref_probe2.cpp): get_random_float (src/TkMath.h:312-319) constructs an
+# unseeded generator per call, so nothing that calls it can be compared number by number.  It becomes a
+# dispatcher: with tk::probe_draw_hook set it returns that function's next number, otherwise it runs
+# upstream's own body (renamed, untouched).  ref_probe.cpp never sets the hook: its fixtures do not change.
+sed -i 's/^\tinline float get_random_float()$/\textern float (*probe_draw_hook)();\n\tinline float get_random_float_unfed();\n\tinline float get_random_float() { return probe_draw_hook ? probe_draw_hook() : get_random_float_unfed(); }\n\tinline float get_random_float_unfed()/' "$S/TkMath.h"
+grep -q 'probe_draw_hook' "$S/TkMath.h" || { echo "build_ref.sh: get_random_float not found where expected"; exit 1; }
 INC="-include cstring -include cstdio -include memory -include array -include functional -include cstdint \
  -include algorithm -include math.h -include mutex -include condition_variable -include thread"
 FLAGS="-std=c++17 -O3 -w -fPIC -DGLEW_NO_GLU $INC -I$S -I$S/core -I$S/tracer -I$REF/external/include"
@@ -41,6 +47,11 @@ for f in $SRCS; do
     if [ ${#pids[@]} -ge 8 ]; then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-g++ $FLAGS -c "$HERE/ref_probe.cpp" -o "$S/obj/ref_probe.o"
-g++ -o "$OUT/ref_probe" "$S"/obj/*.o -lpthread -Wl,--unresolved-symbols=ignore-all
+mkdir -p "$S/probe"
+g++ $FLAGS -c "$HERE/ref_probe.cpp" -o "$S/probe/ref_probe.o"
+g++ -o "$OUT/ref_probe" "$S"/obj/*.o "$S/probe/ref_probe.o" -lpthread -Wl,--unresolved-symbols=ignore-all
 echo "built $OUT/ref_probe"
+# the second prober takes upstream's TkSPPM.cpp in by #include (it is not in upstream's build list, see above)
+g++ $FLAGS -c "$HERE/ref_probe2.cpp" -o "$S/probe/ref_probe2.o"
+g++ -o "$OUT/ref_probe2" "$S"/obj/*.o "$S/probe/ref_probe2.o" -lpthread -Wl,--unresolved-symbols=ignore-all
+echo "built $OUT/ref_probe2"

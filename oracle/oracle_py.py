@@ -34,6 +34,8 @@ def lib():
         "orc_hash_pixel": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
         "orc_permutation_element": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32]),
         "orc_rng_u01": (C.c_float, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "orc_photon_draws": (None, [C.c_uint32, C.c_int, C.c_uint64, C.c_int64, C.c_int, f32p]),
+        "orc_pt_draws": (None, [C.c_uint32, C.c_int, C.c_int64, C.c_int, f32p]),
         "orc_direction_tables": (None, [f32p, f32p, f32p, f32p]),
         "orc_encode_direction": (None, [f32p, u8p, u8p]),
         "orc_pixel_update": (None, [C.c_int64, f32p, f32p, f32p, f32p, i32p, f32p]),
@@ -73,6 +75,7 @@ def lib():
         "orc_sppm_resolve": (None, [C.c_void_p, u8p]),
         "orc_hsppm_iteration": (None, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
         "orc_hsppm_resolve": (None, [C.c_void_p, u8p]),
+        "orc_hg_cells": (None, [f32p, i32p, C.c_uint32, C.c_int64, f32p, i32p, i32p, i32p]),
         "orc_pt_render": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p]),
         "orc_pt_resolve": (None, [f32p, f32p, C.c_int, C.c_int, u8p]),
         "orc_sppm_read_photons": (C.c_int64, [C.c_void_p, C.c_int, f32p, f32p, u8p, u8p, i64p]),
@@ -90,6 +93,19 @@ def lib():
 
 def fp(a):
     return a.ctypes.data_as(f32p)
+
+
+def photon_draws(seed, kind, h0, n, per):
+    """(n, per) float32: what light paths h0 .. h0+n-1 of `kind` draw where the reference calls get_random_float()."""
+    out = np.empty((n, per), np.float32)
+    lib().orc_photon_draws(seed, kind, h0, n, per, fp(out))
+    return out
+
+
+def pt_draws(seed, sample, n_pixels, per):
+    out = np.empty((n_pixels, per), np.float32)
+    lib().orc_pt_draws(seed, sample, n_pixels, per, fp(out))
+    return out
 
 
 def ip(a):

@@ -59,6 +59,10 @@
 
 using namespace tk;
 
+// build_ref.sh turns get_random_float into a dispatcher over this pointer (for ref_probe2.cpp); it stays unset
+// here, so every call runs upstream's own body.
+namespace tk { float (*probe_draw_hook)() = nullptr; }
+
 // ------------------------------------------------------------------ npy out
 static std::string g_out;
 static void save_npy(const std::string& name, const char* descr, const std::vector<size_t>& shape, const void* data,

@@ -1441,6 +1441,29 @@ static float photon_rng(const orc_sppm* r, uint64_t H, int kind, int bounce, int
     return orc_rng_u01(r->seed, (uint32_t)H, b, (uint32_t)slot);
 }
 
+/* The numbers light path H of `kind` (0 global, 1 caustic, 2 hash-grid variant) draws where the reference
+ * calls get_random_float(), in the reference's call order: the triangle pick inside AreaLight::sample_Le
+ * (src/Triangle.cpp:192), then the Russian-roulette number of bounce 0, 1, ... (src/tracer/TkSppmTracer.cpp:144,
+ * :204; src/TkSPPM.cpp:236).  Row i of out (per numbers) is path H0 + i.  Fed to the reference's own loops they
+ * make it trace the paths this port (and the HIP kernels) trace for the same indices. */
+void orc_photon_draws(uint32_t seed, int kind, uint64_t H0, int64_t n, int per, float* out) {
+    orc_sppm r; memset(&r, 0, sizeof(r));
+    r.seed = seed;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t H = H0 + (uint64_t)i;
+        float* row = out + i * per;
+        if (per > 0) row[0] = photon_rng(&r, H, kind, 0, 0);
+        for (int b = 0; b + 1 < per; ++b) row[1 + b] = photon_rng(&r, H, kind, b, 1);
+    }
+}
+/* Likewise the roulette numbers of PathTracer::Li (src/tracer/TkPathTracer.cpp:165) for sample `sample` of
+ * pixels 0 .. n-1: row p holds the numbers of bounce 0 .. per-1. */
+void orc_pt_draws(uint32_t seed, int sample, int64_t n, int per, float* out) {
+    for (int64_t p = 0; p < n; ++p)
+        for (int b = 0; b < per; ++b)
+            out[p * per + b] = orc_rng_u01(seed, (uint32_t)p, (uint32_t)sample, 0x10000u + (uint32_t)b);
+}
+
 /* tracePhoton (kind 0, src/tracer/TkSppmTracer.cpp:104-157) and
  * traceCausticPhoton (kind 1, :159-217).  Photons are returned in recs instead
  * of being pushed into the shared map; the caller appends them in path order. */
@@ -1835,9 +1858,10 @@ void orc_sppm_counters(orc_sppm* r, int64_t* sg, int64_t* sc, int32_t* nr) {
  * tk::SPPM (src/TkSPPM.h:10-64, src/TkSPPM.cpp:19-272, :347-465): visible point per pixel, spatial
  * hash grid over the visible points, photons deposited into the pixels they reach, per-pixel
  * radius reduction.  The class is not part of the reference's build (absent from
- * src/CMakeLists.txt, its line in src/TkLoader.cpp:250 commented out, written against an older
- * RayTracer interface), so no reference output exists for it: PARITY UNPINNED beyond the building
- * blocks it shares with SppmTracer (intersection, materials, light sampling, samplers).
+ * src/CMakeLists.txt, its line in src/TkLoader.cpp:250 commented out), but its translation unit compiles
+ * with the rest: oracle/ref_probe2.cpp takes it in and runs its passes one by one with the unseeded
+ * draws fed in, and tests/golden/ref_hsppm.npz pins this restatement to it (hash, worldToGrid, the pixel
+ * state after the ray, photon and renew passes of two iterations).
  * An orc_sppm created with causticSize 0 carries the state; the TkSPPMPixel fields are reused:
  * Ld = Ld, causticFlux = Tau, causticPhotons = N, causticRadius2 = radius (not squared). */
 typedef struct { v3 p, n, wo, thr; const TkMaterial* m; float radius; int pixel; } VisPoint;
@@ -1858,6 +1882,21 @@ static int hg_world_to_grid(const HashGrid* g, v3 p, int pi[3]) {            /* 
         pi[i] = pi[i] < 0 ? 0 : (pi[i] > g->res[i] - 1 ? g->res[i] - 1 : pi[i]);
     }
     return in;
+}
+
+/* SpatialHashGrids::worldToGrid + hash for n points in a grid of the given bounds (min xyz, max xyz) and
+ * resolution, hashed into `buckets` lists: cell[3n], inside[n], hash[n].  For the parity tests. */
+void orc_hg_cells(const float bounds[6], const int32_t res[3], uint32_t buckets, int64_t n, const float* points,
+                  int32_t* cell, int32_t* inside, int32_t* hash) {
+    HashGrid g;
+    g.b.mn = V(bounds[0], bounds[1], bounds[2]); g.b.mx = V(bounds[3], bounds[4], bounds[5]);
+    g.res[0] = res[0]; g.res[1] = res[1]; g.res[2] = res[2]; g.valid = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        int pi[3];
+        inside[i] = hg_world_to_grid(&g, V(points[3 * i], points[3 * i + 1], points[3 * i + 2]), pi);
+        cell[3 * i] = pi[0]; cell[3 * i + 1] = pi[1]; cell[3 * i + 2] = pi[2];
+        hash[i] = (int32_t)hg_hash(pi[0], pi[1], pi[2], buckets);
+    }
 }
 
 /* One pixel of SPPM::traceTile, src/TkSPPM.cpp:140-177.  Returns 1 with *vp filled when the path

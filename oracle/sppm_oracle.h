@@ -35,6 +35,9 @@ float orc_radical_inverse(int32_t base_index, uint64_t a);
 uint64_t orc_hash_pixel(int32_t x, int32_t y, int32_t dim, int32_t seed);
 int32_t orc_permutation_element(uint32_t i, uint32_t l, uint32_t p);
 float orc_rng_u01(uint32_t seed, uint32_t a, uint32_t b, uint32_t c);
+/* what a light path / a PathTracer::Li sample draws where the reference calls get_random_float(), in its call order */
+void orc_photon_draws(uint32_t seed, int kind, uint64_t H0, int64_t n, int per, float* out);
+void orc_pt_draws(uint32_t seed, int sample, int64_t n, int per, float* out);
 void orc_direction_tables(float* cos_theta, float* sin_theta, float* cos_phi, float* sin_phi);
 void orc_encode_direction(const float wo[3], uint8_t* theta, uint8_t* phi);
 void orc_pixel_update(int64_t n, float* flux, float* photons, float* radius2,
@@ -141,6 +144,8 @@ int orc_sppm_camera_path(orc_sppm* r, int iter, int x, int y, float ld_out[3], O
  * stats: visible points, grid entries, photon deposits. */
 void orc_hsppm_iteration(orc_sppm* r, int spp, int iter, int64_t stats[3]);
 void orc_hsppm_resolve(orc_sppm* r, uint8_t* out);
+void orc_hg_cells(const float bounds[6], const int32_t res[3], uint32_t buckets, int64_t n, const float* points,
+                  int32_t* cell, int32_t* inside, int32_t* hash);
 
 /* --- path tracer, PathTracer::Li + the headless program's film (box filter of radius 0.5) on the
  * scene, depth, roulette probability and seed of an orc_sppm.  contrib: 3 floats per pixel,

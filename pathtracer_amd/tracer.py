@@ -443,6 +443,9 @@ class HashGridSppm:
         check(lib, lib.tkhip_hsppm_begin(self.ctx.h, C.byref(param), spp, max_depth, rr, seed), "tkhip_hsppm_begin")
         self.cur = 0
 
+    def set_jitter(self, on):
+        check(self.ctx.lib, self.ctx.lib.tkhip_sppm_set_jitter(self.ctx.h, 1 if on else 0), "tkhip_sppm_set_jitter")
+
     def iteration(self, it=None):
         it = self.cur if it is None else it
         st = _abi.TkIterStats()

@@ -75,3 +75,43 @@ def assert_pixels_match(px, ref):
     assert bits_equal(px[:, 0:3], ref[:, 0:3]), "Ld"
     assert bits_equal(px[:, 9:13], ref[:, 9:13]), "photon counts / radii"
     np.testing.assert_allclose(px[:, 3:9], ref[:, 3:9], rtol=1e-5, atol=1e-12)
+
+
+def assert_paths_match(g, prefix, pos, power, theta, phi, shot):
+    """A photon pass against upstream's light-path loops (ref_photon_paths.npz): the pass stopped at the path that
+    filled the map upstream, every direction byte pair is equal, positions and powers are equal up to the last bit
+    of the float trigonometry (most of them bit for bit)."""
+    count = g[prefix + "_count"]
+    assert shot == int(np.nonzero(count)[0][-1]) + 1, "the path that stored the last photon"
+    assert len(pos) == int(count.sum())
+    rp, rw, rd = g[prefix + "_pos"], g[prefix + "_power"], g[prefix + "_dir"]
+    assert (np.stack([theta, phi], 1) == rd).all(), "direction bytes"
+    assert bits_equal(pos, rp, per_row=True).mean() > 0.95 and bits_equal(power, rw, per_row=True).mean() > 0.95
+    np.testing.assert_allclose(pos, rp, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(power, rw, rtol=1e-5, atol=1e-12)
+
+
+def float_image(px, counters, W, H):
+    """The colour of every pixel before clamp and gamma (src/tracer/TkSppmTracer.cpp:522-524) from an SPPMPixel array
+    (n, 13) and (shootGlobal, shootCaustic, numRecurse); the caustic term only when caustic photons were shot."""
+    sg, sc, nr = counters
+    px = px.astype(np.float64)
+    img = px[:, 0:3] / nr + px[:, 6:9] / (np.pi * px[:, 12:13] * sg)
+    if sc > 0:
+        img = img + px[:, 3:6] / (np.pi * px[:, 11:12] * sc)
+    return img.reshape(H, W, 3)
+
+
+def hsppm_state_close(px, g, prefix, exact):
+    """Pixel state of the hash-grid variant (Ld 0:3, Tau 3:6, N 9, radius 11) against upstream's after the same
+    iteration.  exact: bit for bit (Tau 1e-5); otherwise all but a per cent of the pixels."""
+    ld, tau, N, rad = g[prefix + "Ld"], g[prefix + "Tau"], g[prefix + "N"], g[prefix + "radius"]
+    same_n = px[:, 9] == N
+    same_r = bits_equal(px[:, 11], rad, per_row=True)
+    same_ld = bits_equal(px[:, 0:3], ld, per_row=True)
+    close_tau = np.isclose(px[:, 3:6], tau, rtol=1e-5, atol=1e-12).all(1)
+    if exact:
+        assert same_n.all() and same_r.all() and same_ld.all() and close_tau.all()
+    else:
+        for m in (same_n, same_r, same_ld, close_tau):
+            assert m.mean() >= 0.99, m.mean()

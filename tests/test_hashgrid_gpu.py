@@ -1,6 +1,6 @@
 """The hash-grid SPPM variant (tk::SPPM, src/TkSPPM.cpp) on the GPU against its restatement in the oracle.
-The class is not part of the reference's build, so beyond the building blocks it shares with SppmTracer
-(pinned in test_ref_pinned_*) PARITY IS UNPINNED: the oracle restates the source text.
+The class is not part of the reference's build, but it compiles with it: tests/test_ref_loops_cpu.py and
+tests/test_ref_loops_gpu.py hold the oracle and the kernels to its own passes (tests/golden/ref_hsppm.npz).
 Bars: Ld, N and the radius of every pixel bit for bit (the photon counts M behind them are integers);
 Tau to 1e-5 relative (photons arrive in another order, so the float sums differ in their last bits)."""
 import numpy as np

@@ -1,8 +1,8 @@
 """tk::PathTracer (src/tracer/TkPathTracer.cpp) on the GPU against its restatement in the oracle: film sums of every
 pixel to 1e-5 relative (the GPU adds a path's contributions hit by hit with atomics, the oracle path by path), the
 filter weight sums exactly, the image to 1 LSB.  The building blocks (intersection, materials, light sampling, the
-stratified sampler, the camera) are pinned to the reference in test_ref_pinned_*; Li itself draws its Russian
-roulette from an unseeded generator there, so the loop as a whole is compared oracle <-> HIP only."""
+stratified sampler, the camera) are pinned to the reference in test_ref_pinned_*, PathTracer::Li as a whole (with its
+unseeded Russian-roulette numbers fed in) in tests/test_ref_loops_cpu.py / test_ref_loops_gpu.py."""
 import numpy as np
 import pytest
 
