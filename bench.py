@@ -205,8 +205,8 @@ def report(args, name, scene, W, H, param, max_depth, rr, seed, world, ranks_see
     # Algorithmic bytes of a gather: 56 B query + 26 B per photon found + 40 B pixel slice.
     # The grouped kernel finishes the gathers that met fewer than k photons; the others end
     # with exactly k photons in the per-query kernel and are not charged to it here.
-    # Measured over the timed region: every launch of the kernel is bracketed by HIP events on
-    # the stream it runs on (the two maps' launches of a step run side by side there).
+    # Measured over the timed region: every launch of the kernel (one per step: it takes the groups of both
+    # maps' gathers) is bracketed by HIP events on the stream it runs on.
     k_g, k_c = param.globalSample, param.causticSample
     done = gt["queries"] - gt["handed_on"][0] - gt["handed_on"][1]
     phot_group = gt["photons_found"] - k_g * gt["handed_on"][0] - k_c * gt["handed_on"][1]
@@ -264,9 +264,10 @@ def report(args, name, scene, W, H, param, max_depth, rr, seed, world, ranks_see
                      "gathers_per_launch": gt["queries"] / launches, "finished_per_launch": done / launches,
                      "distance_tests_per_gather": gt["photons_staged"] * 64.0 / max(gt["queries"], 1.0),
                      "side_by_side": side,
-                     "alone": {"achieved": alone, "frac": alone / HBM_PEAK_GBS, "avg_launch_ms": ms_group / 2.0,
-                               "note": "the same kernel with the GPU to itself (instrumented iterations after the "
-                                       "timed region, the two maps one after the other)"}},
+                     "alone": {"achieved": alone, "frac": alone / HBM_PEAK_GBS, "avg_launch_ms": ms_group,
+                               "note": "the same launch in the instrumented iterations after the timed region (the host "
+                                       "waits for it before it enqueues the per-query kernels)"},
+                     "note": "one launch of k_gather_group per step takes the groups of both maps' gathers"},
     }
     # The whole gather phase (query sort, both gather kernels of both maps, the fused pixel update), from the
     # instrumented iterations: every gather's 56 B query + 26 B per photon found + 40 B pixel slice.
@@ -283,7 +284,7 @@ def report(args, name, scene, W, H, param, max_depth, rr, seed, world, ranks_see
     # rays over the time its two kernels take, the light lanes' over theirs (the lanes run side by side).
     rays_cam, rays_light = vals["rays_camera"], vals["rays"] - vals["rays_camera"]
     c_cam, c_light = vals["counted_rays_camera"], vals["counted_rays"] - vals["counted_rays_camera"]
-    if rays_cam > 0 and c_cam > 0 and vals["node_visits_camera"] > 0:
+    if world == 1 and rays_cam > 0 and c_cam > 0 and vals["node_visits_camera"] > 0:
         def lane(rays, counted, nodes, prims, ms, kernels):
             nodes, prims = nodes / max(counted, 1.0) * rays, prims / max(counted, 1.0) * rays   # per ray of the counted iteration
             per_ray = 32.0 + 48.0 + 64.0 * nodes / max(rays, 1.0) + 48.0 * prims / max(rays, 1.0)

@@ -235,10 +235,11 @@ int tkhip_sppm_set_map_photons(tkhip_ctx* ctx, int which, const float* pos, cons
  * rank): a header with its photon counts and shot counters, then both maps' arrays.
  * tkhip_sppm_export_exchange writes this rank's buffer (DEVICE memory) on the caller's stream (a hipStream_t,
  * 0 = the null stream) and does not wait: the collective the caller enqueues behind it on that stream is
- * ordered, and the rank's next photon pass waits for the copies by an event.
+ * ordered, and the rank's next photon pass waits for the copies.
  * tkhip_sppm_import_exchange takes all ranks' buffers back to back (world * words_per_rank words, DEVICE, as
- * the all-gather delivers them on `stream`) and installs both maps on the device: the counts come from the
- * headers there, the host assumes that every rank met its quota and enqueues the builds at once;
+ * the all-gather delivers them on `stream`), waits until `stream` has got that far and installs both maps on
+ * the device: the host reads nothing of the buffer, the counts come from the headers on the device, the host
+ * assumes that every rank met its quota and enqueues the builds at once;
  * tkhip_sppm_build_maps then checks that assumption against what the device summed (and rebuilds a map that
  * came out smaller), and adds the ranks' shot counters to the cumulative ones. */
 int tkhip_sppm_exchange_words(tkhip_ctx* ctx, int64_t* words_per_rank);

@@ -108,5 +108,11 @@ int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const Gathe
 // The same with the scratch given by the caller (nothing is allocated).
 int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed,
                   const GatherScratch& sc);
+// Scratch of a production gather from the map's own buffers (grown on demand).
+int map_gather_scratch(tkhip_map* m, int64_t nq, GatherScratch* out_sc);
+// Production gathers of two maps (both with queries) whose grouped kernel is one launch; the launch is timed
+// under m0.  Work is left enqueued on the two maps' streams.
+int map_gather_pair(tkhip_map* m0, int64_t nq0, const QueryView& qv0, const GatherOut& out0, tkhip_map* m1, int64_t nq1,
+                    const QueryView& qv1, const GatherOut& out1, bool timed);
 
 }  // namespace tkd

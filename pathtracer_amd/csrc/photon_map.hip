@@ -961,10 +961,24 @@ constexpr int kSelHeavyPercent = 75;       // share of a map's last launch that 
 constexpr int kSelHeavyPercentLarge = 25;  // long leaf lists taken; in a map of more than kSelLargeMap photons
 static_assert(kSelStash <= kSelBins / 2, "the stash of a lane reuses the words of its histogram");
 
+// Everything the grouped kernel needs of one map's gather.  A launch takes one or two of them: the gathers of
+// the two maps of a render (radiance_estimate on the caustic and on the global map, src/tracer/TkSppmTracer.cpp:323,
+// :342) are independent and their groups are dealt to the waves of ONE grid, the first job's groups first.
+struct GroupJob {
+    MapView mv;
+    QueryView qv;
+    SortedQueries qs;
+    const uint32_t* order;
+    int64_t nq;
+    GatherOut out;
+    int32_t* overflow;
+    int32_t* overflow_count;
+    GroupLeaves gl;
+    SelectWork sw;
+    int sel_min_lanes;
+};
 template <bool WANT_IDX>
-__global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView qv, SortedQueries qs, const uint32_t* order,
-                                                      int64_t nq, GatherOut out, int32_t* overflow, int32_t* overflow_count,
-                                                      GroupLeaves gl, SelectWork sw, int sel_min_lanes) {
+__global__ void __launch_bounds__(256, 5) k_gather_group(GroupJob job0, GroupJob job1, int64_t ngroups0, int64_t ngroups_all) {
     constexpr int FCAP = kGroupLeafStride;
     __shared__ float s_tab[1024];
     // candidates of the current step, struct of arrays so that four of them load as one float4
@@ -973,27 +987,29 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
     __shared__ __align__(16) float s_z[4][64];
     __shared__ float4 s_rec[4][64][2];   // (wi.xyz, power.r) (power.g, power.b, original index, -)
     __shared__ int s_front[4][2][FCAP];
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = mv.dirtab[i];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_tab[i] = job0.mv.dirtab[i];   // one table for every map of a context
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int leaf_slot = lane / kLeafCap, ph = lane % kLeafCap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int k = mv.k;
-    const int64_t ngroups = (nq + 63) >> 6;
+    const int64_t ngroups = ngroups_all;
     int (*front)[FCAP] = s_front[wave];
-    const float4 root0 = mv.node_box[2], root1 = mv.node_box[3];   // box of the whole map (heap node 1)
-    unsigned long long found_sum = 0, staged_sum = 0;
-    int flagged_sum = 0;     // queries of this wave that met k photons or more (what the next launch goes by)
-    const bool heavy = sw.heavy != 0;
+    // per job: photons found by the queries finished here, photons staged, queries that met k photons or more
+    unsigned long long found_sum[2] = {0, 0}, staged_sum[2] = {0, 0};
+    int flagged_sum[2] = {0, 0};
     // Groups are handed out one at a time: the waves of the grid (sized to what the GPU holds at once)
     // stay busy until the last group is taken.  Two group indices are kept ahead of the one being worked
     // on, and the queries of the next group are loaded while the current one is worked on, so that a
     // group does not start with a chain of memory round trips.
     struct Pre { float4 a, b; int q, pixel; float r2s; bool valid; };
-    auto prefetch = [&](int64_t g) {
+    auto prefetch = [&](int64_t g_all) {
         Pre P;
-        const int64_t slot = g * 64 + lane;
-        P.valid = g < ngroups && slot < nq;
+        const bool second = g_all >= ngroups0;
+        const SortedQueries& qs = second ? job1.qs : job0.qs;
+        const uint32_t* order = second ? job1.order : job0.order;
+        const int64_t nq = second ? job1.nq : job0.nq;
+        const int64_t slot = (g_all - (second ? ngroups0 : 0)) * 64 + lane;
+        P.valid = g_all < ngroups && slot < nq;
         P.a = make_float4(0, 0, 0, -1.f); P.b = make_float4(0, 0, 0, 0); P.q = 0; P.pixel = 0; P.r2s = -1.f;
         if (P.valid) {
             P.a = qs.q0[slot]; P.b = qs.q1[slot];          // in the order of the curve: coalesced
@@ -1027,9 +1043,25 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
 #endif
     Pre cur_q = prefetch((int64_t)uniform_i(gi0));
     while (true) {
-        const int64_t g = (int64_t)uniform_i(gi0);
+        const int64_t g_all = (int64_t)uniform_i(gi0);
         TK_STAMP(0)
-        if (g >= ngroups) break;
+        if (g_all >= ngroups) break;
+        // the job this group belongs to (wave-uniform): its arguments are read from the kernel's argument block
+        const int jb = g_all >= ngroups0 ? 1 : 0;
+        const GroupJob& J = jb ? job1 : job0;
+        const int64_t g = g_all - (jb ? ngroups0 : 0);
+        const MapView mv = J.mv;
+        const QueryView qv = J.qv;
+        const int64_t nq = J.nq;
+        const GatherOut out = J.out;
+        int32_t* const overflow = J.overflow;
+        int32_t* const overflow_count = J.overflow_count;
+        const GroupLeaves gl = J.gl;
+        const SelectWork sw = J.sw;
+        const int sel_min_lanes = J.sel_min_lanes;
+        const int k = mv.k;
+        const bool heavy = sw.heavy != 0;
+        const float4 root0 = mv.node_box[2], root1 = mv.node_box[3];   // box of the whole map (heap node 1)
         const int gi2 = next_index();
         const Pre next_q = prefetch((int64_t)uniform_i(gi1));
         const bool valid = cur_q.valid;
@@ -1163,7 +1195,7 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
                 const int n_in = stage(has, pp, pw);
                 const int n4 = (n_in + 3) & ~3;
                 has = i + kLeavesPerStep < fcount ? fetch(i + kLeavesPerStep, &pp, &pw) : false;
-                staged_sum += (unsigned long long)n_in;
+                staged_sum[jb] += (unsigned long long)n_in;
                 // A: candidate c ends up at bit n4 - 1 - c of the 64-bit mask (m1 : m0)
                 uint32_t m0 = 0, m1 = 0;
                 for (int c = 0; c < n4; c += 4) {
@@ -1272,19 +1304,25 @@ __global__ void __launch_bounds__(256, 5) k_gather_group(MapView mv, QueryView q
             for (int e = lane; e < fcount; e += 64) gl.leaves[g * kGroupLeafStride + e] = front[cur][e];
             if (lane == 0) gl.count[g] = fcount;
         }
-        flagged_sum += __popcll(__ballot(valid && Q.r2 > 0.f && (cnt >= k || spread)));
+        flagged_sum[jb] += __popcll(__ballot(valid && Q.r2 > 0.f && (cnt >= k || spread)));
         if (defer_group) {
             const int64_t slot = g * 64 + lane;
             if (slot < nq) sw.slot_cnt[slot] = deferred ? cnt : -1;
             if (lane == 0) sw.groups[atomicAdd(sw.count, 1)] = (int32_t)g;
         }
         cur_q = next_q; gi0 = gi1; gi1 = gi2;
-        found_sum += (unsigned long long)wave_sum_all(fin ? (float)cnt : 0.f);
+        found_sum[jb] += (unsigned long long)wave_sum_all(fin ? (float)cnt : 0.f);
         TK_STAMP(4)
     }
-    if (out.photon_sum && lane == 0 && found_sum) atomicAdd(out.photon_sum, found_sum);
-    if (out.cand_sum && lane == 0 && staged_sum) atomicAdd(out.cand_sum, staged_sum);
-    if (sw.met_k && lane == 0 && flagged_sum) atomicAdd(sw.met_k, flagged_sum);
+    for (int jb = 0; jb < 2; ++jb) {
+        const GroupJob& J = jb ? job1 : job0;
+        if (J.out.photon_sum && lane == 0 && found_sum[jb]) atomicAdd(J.out.photon_sum, found_sum[jb]);
+        if (J.out.cand_sum && lane == 0 && staged_sum[jb]) atomicAdd(J.out.cand_sum, staged_sum[jb]);
+        if (J.sw.met_k && lane == 0 && flagged_sum[jb]) atomicAdd(J.sw.met_k, flagged_sum[jb]);
+    }
+#if defined(TK_GG_TURNS) || defined(TK_GG_STAMPS)
+    const GatherOut& out = job0.out;   // the profiling builds below report through the first job
+#endif
 #ifdef TK_GG_TURNS
     if (out.photon_sum && lane == 0) {
         atomicAdd(out.photon_sum + 9, tn_half); atomicAdd(out.photon_sum + 10, tn_step); atomicAdd(out.photon_sum + 11, tn_pair);
@@ -1832,32 +1870,39 @@ int map_flush_timing(tkhip_map* m) {
     return TKHIP_OK;
 }
 
+// The scratch of a production gather of nq queries on a map's own buffers, and the decision the map's last
+// launch leaves for this one.
+int map_gather_scratch(tkhip_map* m, int64_t nq, GatherScratch* out_sc) {
+    GatherScratch sc{};
+    TK_TRY(map_reserve_queries(m, nq));
+    sc.q_keys_a = m->q_keys_a.as<uint32_t>(); sc.q_keys_b = m->q_keys_b.as<uint32_t>();
+    sc.q_vals_a = m->q_vals_a.as<uint32_t>(); sc.q_order = m->q_order.as<uint32_t>();
+    sc.overflow = m->overflow.as<int32_t>(); sc.overflow_group = m->overflow_group.as<int32_t>();
+    sc.group_leaves = m->group_leaves.as<int32_t>(); sc.group_leaf_count = m->group_leaf_count.as<int32_t>();
+    sc.sel_groups = m->sel_groups.as<int32_t>(); sc.sel_cnt = m->sel_cnt.as<int32_t>(); sc.q_r2s = m->q_r2s.as<float>();
+    // Many gathers of the map's last launch met k photons (or there was none yet): radii are cut first and long
+    // leaf lists taken.  The count of that launch has arrived long ago; the wait is for form.
+    static const int heavy_pct_env = getenv("TKHIP_HEAVY_PCT") ? atoi(getenv("TKHIP_HEAVY_PCT")) : 0;
+    const int heavy_pct = heavy_pct_env > 0 ? heavy_pct_env : (m->n > kSelLargeMap ? kSelHeavyPercentLarge : kSelHeavyPercent);
+    sc.heavy = 1;
+    if (m->met_k_pending) {
+        TK_HIP(hipEventSynchronize(m->ev_met_k));
+        sc.heavy = (int64_t)m->met_k_host[0] * 100 >= m->met_k_queries * heavy_pct ? 1 : 0;
+    }
+    sc.track = 1;
+    sc.counter = m->counters.as<int32_t>();
+    sc.q_sorted = m->q_sorted.as<float4>();
+    sc.sort_temp = m->prim_temp.p; sc.sort_temp_bytes = m->prim_temp.bytes;
+    *out_sc = sc;
+    return TKHIP_OK;
+}
+
 int map_gather_device(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed) {
     TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
     if (nq == 0) return TKHIP_OK;
     TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
     GatherScratch sc{};
-    if (mode == 0) {
-        TK_TRY(map_reserve_queries(m, nq));
-        sc.q_keys_a = m->q_keys_a.as<uint32_t>(); sc.q_keys_b = m->q_keys_b.as<uint32_t>();
-        sc.q_vals_a = m->q_vals_a.as<uint32_t>(); sc.q_order = m->q_order.as<uint32_t>();
-        sc.overflow = m->overflow.as<int32_t>(); sc.overflow_group = m->overflow_group.as<int32_t>();
-        sc.group_leaves = m->group_leaves.as<int32_t>(); sc.group_leaf_count = m->group_leaf_count.as<int32_t>();
-        sc.sel_groups = m->sel_groups.as<int32_t>(); sc.sel_cnt = m->sel_cnt.as<int32_t>(); sc.q_r2s = m->q_r2s.as<float>();
-        // Many gathers of the map's last launch met k photons (or there was none yet): radii are cut first and long
-        // leaf lists taken.  The count of that launch has arrived long ago; the wait is for form.
-        static const int heavy_pct_env = getenv("TKHIP_HEAVY_PCT") ? atoi(getenv("TKHIP_HEAVY_PCT")) : 0;
-        const int heavy_pct = heavy_pct_env > 0 ? heavy_pct_env : (m->n > kSelLargeMap ? kSelHeavyPercentLarge : kSelHeavyPercent);
-        sc.heavy = 1;
-        if (m->met_k_pending) {
-            TK_HIP(hipEventSynchronize(m->ev_met_k));
-            sc.heavy = (int64_t)m->met_k_host[0] * 100 >= m->met_k_queries * heavy_pct ? 1 : 0;
-        }
-        sc.track = 1;
-        sc.counter = m->counters.as<int32_t>();
-        sc.q_sorted = m->q_sorted.as<float4>();
-        sc.sort_temp = m->prim_temp.p; sc.sort_temp_bytes = m->prim_temp.bytes;
-    }
+    if (mode == 0) TK_TRY(map_gather_scratch(m, nq, &sc));
     return map_gather_in(m, nq, qv, out, mode, timed, sc);
 }
 
@@ -1896,25 +1941,14 @@ static int select_grid_blocks(int device) {
     return cached[device];
 }
 
-int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed,
-                  const GatherScratch& sc) {
-    TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
-    if (nq == 0) return TKHIP_OK;
-    TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
+// A gather in three parts, so that the grouped kernel of two maps can be one launch:
+//   gather_prepare  (the map's stream)  query order along the curve, radii cut where they hold many times k photons;
+//   gather_group    (one stream)        the grouped kernel over the jobs of one or two maps;
+//   gather_finish   (the map's stream)  the selection kernel (while many gathers meet k photons) and the
+//                                       per-query kernel for what was handed on.
+static int gather_prepare(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, const GatherScratch& sc,
+                          GroupJob* job) {
     hipStream_t s = m->stream;
-    const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
-    auto wave_all = [&](const int32_t* list, const int32_t* cnt, int64_t hint, const GroupLeaves& gl) {
-        if (epl == 2) launch_wave<2>(m, qv, list, cnt, nq, hint, out, gl);
-        else if (epl == 4) launch_wave<4>(m, qv, list, cnt, nq, hint, out, gl);
-        else launch_wave<8>(m, qv, list, cnt, nq, hint, out, gl);
-    };
-    m->last_group_ms = 0.f;
-    m->last_overflow = 0;
-    if (mode == 1) {
-        wave_all(nullptr, nullptr, nq, GroupLeaves{nullptr, nullptr, nullptr});
-        TK_LAUNCH_CHECK();
-        return TKHIP_OK;
-    }
     // Curve order inside the root box of the tree (heap node 1), to the bucket
     const int bits = query_bucket_bits(nq);
     const size_t nb = query_bucket_count(nq);
@@ -1947,49 +1981,68 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
         TK_LAUNCH_CHECK();
     }
     int32_t* ocount = sc.counter;          // the hand-over count
-    // the grid: as many waves as the GPU holds at once (fewer waves with the same number of groups
-    // each were no faster: 0.24 against 0.23 ms per launch)
-    const int64_t groups = (nq + 63) / 64;
-    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), group_grid_blocks(m->ctx->device));
     int32_t* scount = sc.counter + 16;     // groups left to the selection kernel
     TK_HIP(hipMemsetAsync(ocount, 0, 128, s));
-    if (!sc.untimed) {
-        TK_TRY(map_flush_timing(m));
-        TK_HIP(hipEventRecord(m->ev_begin, s));
-    }
-    const GroupLeaves gl{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
     // (the two thresholds can be forced from the environment: tests run every gather through the selection kernel)
     static const int sel_min_env = getenv("TKHIP_SEL_MIN") ? atoi(getenv("TKHIP_SEL_MIN")) : 0;
     // (while few gathers meet k photons no group is left to the selection kernel: it is not even launched)
     const int sel_min = !sc.heavy ? 65 : sel_min_env > 0 ? sel_min_env : (m->n > kSelLargeMap ? kSelMinLanesLarge : kSelMinLanes);
     static const int sel_groups = getenv("TKHIP_SEL_GROUPS") ? atoi(getenv("TKHIP_SEL_GROUPS")) : kSelMinGroups;
-    const SortedQueries qs{sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<const float*>(sc.q_keys_a), sc.q_r2s};   // the keys are done with
-    const SelectWork sw{sc.sel_groups, scount, sc.sel_cnt, sc.track ? sc.counter + 24 : nullptr, sel_groups, sc.heavy};
-    if (out.idx)
-        k_gather_group<true><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
-    else
-        k_gather_group<false><<<blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+    job->mv = m->view();
+    job->qv = qv;
+    job->qs = SortedQueries{sc.q_sorted, sc.q_sorted + nq, reinterpret_cast<const float*>(sc.q_keys_a), sc.q_r2s};   // the keys are done with
+    job->order = sc.q_order;
+    job->nq = nq;
+    job->out = out;
+    job->overflow = sc.overflow;
+    job->overflow_count = ocount;
+    job->gl = GroupLeaves{sc.overflow_group, sc.group_leaves, sc.group_leaf_count};
+    job->sw = SelectWork{sc.sel_groups, scount, sc.sel_cnt, sc.track ? sc.counter + 24 : nullptr, sel_groups, sc.heavy};
+    job->sel_min_lanes = sel_min;
+    return TKHIP_OK;
+}
+
+// The grouped kernel over one or two jobs on `s`, bracketed by the events of `mt` (whose running totals take
+// the launch) unless untimed.  The grid: as many waves as the GPU holds at once (fewer waves with the same
+// number of groups each were no faster: 0.24 against 0.23 ms per launch).
+static int gather_group(tkhip_map* mt, hipStream_t s, const GroupJob* jobs, int n_jobs, bool untimed) {
+    const int64_t g0 = (jobs[0].nq + 63) / 64, g1 = n_jobs > 1 ? (jobs[1].nq + 63) / 64 : 0;
+    const int64_t groups = g0 + g1;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), group_grid_blocks(mt->ctx->device));
+    if (!untimed) {
+        TK_TRY(map_flush_timing(mt));
+        TK_HIP(hipEventRecord(mt->ev_begin, s));
+    }
+    const GroupJob& second = jobs[n_jobs > 1 ? 1 : 0];
+    if (jobs[0].out.idx || second.out.idx) k_gather_group<true><<<blocks, 256, 0, s>>>(jobs[0], second, g0, groups);
+    else k_gather_group<false><<<blocks, 256, 0, s>>>(jobs[0], second, g0, groups);
     TK_LAUNCH_CHECK();
-    if (!sc.untimed) TK_HIP(hipEventRecord(m->ev_end, s));
+    if (!untimed) {
+        TK_HIP(hipEventRecord(mt->ev_end, s));
+        mt->ev_pending = true;
+        mt->group_queries += jobs[0].nq + (n_jobs > 1 ? jobs[1].nq : 0);
+    }
+    return TKHIP_OK;
+}
+
+static int gather_finish(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, bool timed, const GatherScratch& sc,
+                         const GroupJob& job) {
+    hipStream_t s = m->stream;
+    const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
+    const int64_t groups = (nq + 63) / 64;
     // the groups with many lanes at k or above (their number is known to the device only: the waves of a
     // grid that fills the GPU once share them out)
     const int sel_blocks = (int)std::min<int64_t>(std::max<int64_t>(divup(groups, 4), 1), select_grid_blocks(m->ctx->device));
     if (sc.heavy) {
         if (out.idx)
-            k_gather_select<true><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+            k_gather_select<true><<<sel_blocks, 256, 0, s>>>(job.mv, qv, job.qs, job.order, nq, out, job.overflow, job.overflow_count, job.gl, job.sw, job.sel_min_lanes);
         else
-            k_gather_select<false><<<sel_blocks, 256, 0, s>>>(m->view(), qv, qs, sc.q_order, nq, out, sc.overflow, ocount, gl, sw, sel_min);
+            k_gather_select<false><<<sel_blocks, 256, 0, s>>>(job.mv, qv, job.qs, job.order, nq, out, job.overflow, job.overflow_count, job.gl, job.sw, job.sel_min_lanes);
         TK_LAUNCH_CHECK();
     }
-    if (!sc.untimed) {
-        m->ev_pending = true;
-        m->group_queries += nq;
-    }
-    if (timed && !sc.untimed) {
-        TK_HIP(hipEventSynchronize(m->ev_end));
-        TK_HIP(hipEventElapsedTime(&m->last_group_ms, m->ev_begin, m->ev_end));
-    }
-    wave_all(sc.overflow, ocount, nq, gl);
+    if (epl == 2) launch_wave<2>(m, qv, job.overflow, job.overflow_count, nq, nq, out, job.gl);
+    else if (epl == 4) launch_wave<4>(m, qv, job.overflow, job.overflow_count, nq, nq, out, job.gl);
+    else launch_wave<8>(m, qv, job.overflow, job.overflow_count, nq, nq, out, job.gl);
     TK_LAUNCH_CHECK();
     if (sc.track) {
         TK_HIP(hipMemcpyAsync(m->met_k_host, sc.counter + 24, 4, hipMemcpyDeviceToHost, s));
@@ -1999,9 +2052,74 @@ int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut
     }
     if (timed) {
         int32_t oc = 0;
-        TK_HIP(hipMemcpyAsync(&oc, ocount, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(hipMemcpyAsync(&oc, job.overflow_count, 4, hipMemcpyDeviceToHost, s));
         TK_HIP(hipStreamSynchronize(s));
         m->last_overflow = oc;
+    }
+    return TKHIP_OK;
+}
+
+int map_gather_in(tkhip_map* m, int64_t nq, const QueryView& qv, const GatherOut& out, int mode, bool timed,
+                  const GatherScratch& sc) {
+    TK_REQUIRE(m->built, TKHIP_E_STATE, "gather: the KD-tree has not been built");
+    if (nq == 0) return TKHIP_OK;
+    TK_REQUIRE(nq < (int64_t)1 << 31, TKHIP_E_LIMIT, "gather: too many queries");
+    m->last_group_ms = 0.f;
+    m->last_overflow = 0;
+    if (mode == 1) {
+        const int epl = m->k <= 64 ? 2 : (m->k <= 192 ? 4 : 8);
+        const GroupLeaves none{nullptr, nullptr, nullptr};
+        if (epl == 2) launch_wave<2>(m, qv, nullptr, nullptr, nq, nq, out, none);
+        else if (epl == 4) launch_wave<4>(m, qv, nullptr, nullptr, nq, nq, out, none);
+        else launch_wave<8>(m, qv, nullptr, nullptr, nq, nq, out, none);
+        TK_LAUNCH_CHECK();
+        return TKHIP_OK;
+    }
+    GroupJob job{};
+    TK_TRY(gather_prepare(m, nq, qv, out, sc, &job));
+    TK_TRY(gather_group(m, m->stream, &job, 1, sc.untimed != 0));
+    if (timed && !sc.untimed) {
+        TK_HIP(hipEventSynchronize(m->ev_end));
+        TK_HIP(hipEventElapsedTime(&m->last_group_ms, m->ev_begin, m->ev_end));
+    }
+    return gather_finish(m, nq, qv, out, timed, sc, job);
+}
+
+// The gathers of the two maps of a render with ONE launch of the grouped kernel: both maps' queries are put in
+// order on their own streams, the launch (on the first map's stream, timed under the first map) waits for both,
+// and each map's selection and per-query kernels follow on its own stream again.
+int map_gather_pair(tkhip_map* m0, int64_t nq0, const QueryView& qv0, const GatherOut& out0, tkhip_map* m1, int64_t nq1,
+                    const QueryView& qv1, const GatherOut& out1, bool timed) {
+    TK_REQUIRE(m0->built && m1->built, TKHIP_E_STATE, "gather: the KD-trees have not been built");
+    TK_REQUIRE(nq0 > 0 && nq1 > 0 && nq0 < (int64_t)1 << 31 && nq1 < (int64_t)1 << 31, TKHIP_E_ARG, "gather: bad query counts");
+    tkhip_map* ms[2] = {m0, m1};
+    const int64_t nqs[2] = {nq0, nq1};
+    const QueryView* qvs[2] = {&qv0, &qv1};
+    const GatherOut* outs[2] = {&out0, &out1};
+    GatherScratch sc[2];
+    GroupJob jobs[2];
+    for (int w = 1; w >= 0; --w) {
+        ms[w]->last_group_ms = 0.f;
+        ms[w]->last_overflow = 0;
+        TK_TRY(map_gather_scratch(ms[w], nqs[w], &sc[w]));
+        TK_TRY(gather_prepare(ms[w], nqs[w], *qvs[w], *outs[w], sc[w], &jobs[w]));
+    }
+    // The two streams are ordered through the host: it waits for the second map's query order (the first map's
+    // is being made meanwhile), enqueues the launch and the first map's remaining kernels behind it, and gives
+    // the second map's remaining kernels to their stream once the launch has ended.  (Event waits between the
+    // two streams instead were seen to stall for good when several renders share a GPU: the streams of a
+    // process outnumber the hardware queues then.)
+    TK_HIP(hipStreamSynchronize(m1->stream));
+    TK_TRY(gather_group(m0, m0->stream, jobs, 2, false));
+    TK_TRY(gather_finish(m0, nq0, qv0, out0, false, sc[0], jobs[0]));
+    TK_HIP(hipEventSynchronize(m0->ev_end));
+    if (timed) TK_HIP(hipEventElapsedTime(&m0->last_group_ms, m0->ev_begin, m0->ev_end));
+    TK_TRY(gather_finish(m1, nq1, qv1, out1, timed, sc[1], jobs[1]));
+    if (timed) {
+        int32_t oc = 0;
+        TK_HIP(hipMemcpyAsync(&oc, jobs[0].overflow_count, 4, hipMemcpyDeviceToHost, m0->stream));
+        TK_HIP(hipStreamSynchronize(m0->stream));
+        m0->last_overflow = oc;
     }
     return TKHIP_OK;
 }

@@ -34,6 +34,9 @@
 #include "photon_map.h"
 #include "tk_bvh_device.h"
 
+// TKHIP_TRACE=1: the host-side steps of a pass on stderr (to see where a pass is waiting)
+#define TK_TRACE(...) do { static const bool tr_ = getenv("TKHIP_TRACE") != nullptr; if (tr_) { fprintf(stderr, "tkhip trace: " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 namespace tkd {
 
 // Counters of a pass.  Those that many waves hit with atomics at the same time
@@ -162,6 +165,8 @@ struct SppmState {
     hipEvent_t ev_exchange = nullptr, ev_preview = nullptr;
     long long* h_exchange = nullptr;         // pinned: per map the photon count and the light paths shot, summed over the ranks
     bool exchange_pending = false;           // an import has installed maps whose sizes the host has only assumed so far
+    bool export_pending = false;             // an export's copies of this rank's photon arrays may still be running
+    bool preview_pending = false;            // a preview kernel may still be reading the pixel planes
     int64_t exchange_expected[2] = {0, 0};
     DevBuf preview;                  // RGBA8 frame buffer on the device (tkhip_sppm_set_preview)
     int preview_every = 0, preview_iter = -1;
@@ -1240,6 +1245,10 @@ static int photon_pass_begin(tkhip_ctx* ctx, int64_t* B_out) {
     SppmState* s = ctx->sppm;
     Lane& ln = s->lane[KIND];
     *B_out = 0;
+    if (s->export_pending) {   // tkhip_sppm_export_exchange is still copying the arrays this pass overwrites
+        TK_HIP(hipEventSynchronize(s->ev_exchange));
+        s->export_pending = false;
+    }
     if (s->quota[KIND] <= 0) return TKHIP_OK;
     TK_HIP(hipMemsetAsync(&ln.counters.as<int32_t>()[C_RAYS], 0, 24, ln.stream));
     return photon_launch_batch<KIND>(ctx, 0, 0, B_out);
@@ -1314,6 +1323,10 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic, bo
     hipStream_t stream = ln.stream;
     int32_t* counters = ln.counters.as<int32_t>();
     s->camera_in_flight = iter;
+    if (s->preview_pending) {   // a preview of the iteration before still reads the planes (it is a kernel of microseconds)
+        TK_HIP(hipEventSynchronize(s->ev_preview));
+        s->preview_pending = false;
+    }
     if (s->n_slots == 0) return TKHIP_OK;
     CameraArgs a;
     a.sc = ctx->scene; a.cam = ctx->cam;
@@ -1355,6 +1368,7 @@ static int camera_trace_wait(tkhip_ctx* ctx) {
     s->n_queries[0] = s->n_queries[1] = 0;
     if (s->n_slots == 0) return TKHIP_OK;
     TK_HIP(hipStreamSynchronize(ln.stream));
+    TK_TRACE("camera paths done");
     s->n_queries[0] = ln.h_counters[C_NGQ];
     s->n_queries[1] = ln.h_counters[C_NCQ];
     if (getenv("TKHIP_DEBUG_STAMPS")) {   // a profiling build (TK_CP_STAMPS) of k_camera_paths leaves its slowest wave's figures here
@@ -1370,45 +1384,62 @@ static int camera_trace(tkhip_ctx* ctx, int iter, bool expect_caustic) {
     return camera_trace_wait(ctx);
 }
 
-// radiance_estimate + SPPMPixel update for the queries of one map, on that
-// map's stream (the two maps update disjoint planes and can run side by side).
-static int camera_gather(tkhip_ctx* ctx, int which, bool timed) {
+// radiance_estimate + SPPMPixel update for the queries of both maps (the two maps update disjoint planes).
+// The grouped kernel of the two gathers is ONE launch (map_gather_pair): the query order of each map is made
+// on its own stream, the launch takes both maps' groups, and each map's per-query kernel follows on its own
+// stream again.  Everything is enqueued from this thread; both streams have drained when it returns.
+static int camera_gather_both(tkhip_ctx* ctx, bool timed) {
     SppmState* s = ctx->sppm;
-    int64_t nq = s->n_queries[which];
-    if (which == 1 && s->stored_c == 0) nq = 0;   // src/tracer/TkSppmTracer.cpp:323
-    s->n_queries[which] = nq;
-    if (nq == 0) { s->map[which]->last_group_ms = 0.f; s->map[which]->last_overflow = 0; return TKHIP_OK; }
-    float4* q = s->qbuf[s->gather_set][which].as<float4>();
-    QueryView qv{q, q + s->n_slots, q + 2 * s->n_slots, q + 3 * s->n_slots};
-    if (s->stale_radius[s->gather_set]) {
-        // queries written while the gathers of the iteration before were still to come: their search
-        // radii are the pixels' radii of now (this stream ran those gathers)
-        k_query_radius<<<divup(nq, 256), 256, 0, s->map[which]->stream>>>(q, q + 2 * s->n_slots, nq, s->planes.as<float>() +
-                                                                          (which == 0 ? 12 : 11) * s->n_pixels);
-        TK_LAUNCH_CHECK();
+    TK_TRACE("gather_both: nq %lld %lld stored_c %lld timed %d", (long long)s->n_queries[0], (long long)s->n_queries[1], (long long)s->stored_c, (int)timed);
+    int64_t nq[2] = {s->n_queries[0], s->n_queries[1]};
+    if (s->stored_c == 0) nq[1] = 0;   // src/tracer/TkSppmTracer.cpp:323
+    QueryView qv[2];
+    GatherOut out[2];
+    unsigned long long before[2][2] = {{0, 0}, {0, 0}};
+    for (int which = 0; which < 2; ++which) {
+        s->n_queries[which] = nq[which];
+        tkhip_map* m = s->map[which];
+        m->last_group_ms = 0.f;
+        m->last_overflow = 0;
+        if (nq[which] == 0) continue;
+        float4* q = s->qbuf[s->gather_set][which].as<float4>();
+        qv[which] = QueryView{q, q + s->n_slots, q + 2 * s->n_slots, q + 3 * s->n_slots};
+        if (s->stale_radius[s->gather_set]) {
+            // queries written while the gathers of the iteration before were still to come: their search
+            // radii are the pixels' radii of now (this stream ran those gathers)
+            k_query_radius<<<divup(nq[which], 256), 256, 0, m->stream>>>(q, q + 2 * s->n_slots, nq[which], s->planes.as<float>() +
+                                                                         (which == 0 ? 12 : 11) * s->n_pixels);
+            TK_LAUNCH_CHECK();
+        }
+        GatherOut o{};
+        o.planes = s->planes.as<float>();
+        o.n_pixels = s->n_pixels;
+        o.which = which;
+        // running totals of the map (read by tkhip_sppm_gather_totals and, per call, by the stats below)
+        unsigned long long* totals = m->totals.as<unsigned long long>();
+        o.photon_sum = totals;
+        o.cand_sum = totals + 1;
+        o.overflow_sum = totals + 2;
+        out[which] = o;
+        if (timed) {
+            TK_HIP(hipMemcpyAsync(before[which], totals, 16, hipMemcpyDeviceToHost, m->stream));
+            TK_HIP(hipStreamSynchronize(m->stream));
+        }
     }
-    GatherOut out{};
-    out.planes = s->planes.as<float>();
-    out.n_pixels = s->n_pixels;
-    out.which = which;
-    // running totals of the map (read by tkhip_sppm_gather_totals and, per call, by the stats below)
-    unsigned long long* totals = s->map[which]->totals.as<unsigned long long>();
-    out.photon_sum = totals;
-    out.cand_sum = totals + 1;
-    out.overflow_sum = totals + 2;
-    unsigned long long before[2] = {0, 0};
+    if (nq[0] > 0 && nq[1] > 0) TK_TRY(map_gather_pair(s->map[0], nq[0], qv[0], out[0], s->map[1], nq[1], qv[1], out[1], timed));
+    else
+        for (int which = 0; which < 2; ++which)
+            if (nq[which] > 0) TK_TRY(map_gather_device(s->map[which], nq[which], qv[which], out[which], 0, timed));
+    TK_TRACE("gather_both: enqueued");
+    for (int which = 0; which < 2; ++which) { TK_HIP(hipStreamSynchronize(s->map[which]->stream)); TK_TRACE("gather_both: stream %d drained", which); }
     if (timed) {
-        TK_HIP(hipMemcpyAsync(before, totals, 16, hipMemcpyDeviceToHost, s->map[which]->stream));
-        TK_HIP(hipStreamSynchronize(s->map[which]->stream));
-    }
-    TK_TRY(map_gather_device(s->map[which], nq, qv, out, 0, timed));
-    TK_HIP(hipStreamSynchronize(s->map[which]->stream));
-    if (timed) {
-        unsigned long long after[2] = {0, 0};
-        TK_HIP(hipMemcpyAsync(after, totals, 16, hipMemcpyDeviceToHost, s->map[which]->stream));
-        TK_HIP(hipStreamSynchronize(s->map[which]->stream));
-        s->last_gather_photons[which] = (int64_t)(after[0] - before[0]);
-        s->last_gather_staged[which] = (int64_t)(after[1] - before[1]);
+        for (int which = 0; which < 2; ++which) {
+            if (nq[which] == 0) continue;
+            unsigned long long after[2] = {0, 0};
+            TK_HIP(hipMemcpy(after, s->map[which]->totals.p, 16, hipMemcpyDeviceToHost));
+            s->last_gather_photons[which] = (int64_t)(after[0] - before[which][0]);
+            s->last_gather_staged[which] = (int64_t)(after[1] - before[which][1]);
+        }
     }
     return TKHIP_OK;
 }
@@ -1450,38 +1481,7 @@ static int build_both(tkhip_ctx* ctx, double* ms) {
 static int gather_both(tkhip_ctx* ctx, TkIterStats* st) {
     SppmState* s = ctx->sppm;
     double t0 = now_ms();
-    const bool timed = st != nullptr;
-    // Timed (instrumented) calls run the two gathers one after the other so that the event-timed
-    // duration of each grouped kernel is its own; otherwise they share the GPU.
-    Worker w;
-    int rc, rc1 = TKHIP_OK;
-    if (timed) {
-        rc = camera_gather(ctx, 1, true);
-        if (rc == TKHIP_OK) rc = camera_gather(ctx, 0, true);
-    } else {
-        w.start(ctx, [ctx]() { return camera_gather(ctx, 1, false); });
-        rc = camera_gather(ctx, 0, false);
-        rc1 = w.join();
-        // Both streams have drained.  The two grouped kernels ran side by side: the time from the first
-        // one's begin to the last one's end (the events of the two streams share the GPU's clock).
-        tkhip_map *m0 = s->map[0], *m1 = s->map[1];
-        if (rc == TKHIP_OK && rc1 == TKHIP_OK && (m0->ev_pending || m1->ev_pending)) {
-            float d0 = 0.f, d1 = 0.f, b01 = 0.f;
-            bool ok = true;
-            if (m0->ev_pending) ok = ok && hipEventElapsedTime(&d0, m0->ev_begin, m0->ev_end) == hipSuccess;
-            if (m1->ev_pending) ok = ok && hipEventElapsedTime(&d1, m1->ev_begin, m1->ev_end) == hipSuccess;
-            if (m0->ev_pending && m1->ev_pending) ok = ok && hipEventElapsedTime(&b01, m0->ev_begin, m1->ev_begin) == hipSuccess;
-            if (ok) {
-                float span = m0->ev_pending && m1->ev_pending ? std::max(d0, b01 + d1) - std::min(0.f, b01) : (m0->ev_pending ? d0 : d1);
-                s->group_union_ms_total += span;
-                s->group_union_steps += 1;
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-    }
-    if (rc != TKHIP_OK) return rc;
-    if (rc1 != TKHIP_OK) return rc1;
+    TK_TRY(camera_gather_both(ctx, st != nullptr));
     if (st) {
         st->ms_gather += (float)(now_ms() - t0);
         st->ms_gather_kernel += s->map[0]->last_group_ms + s->map[1]->last_group_ms;
@@ -1519,9 +1519,9 @@ static int maybe_preview(tkhip_ctx* ctx, int iter, bool force) {
                                                                s->preview.as<uint32_t>());
     TK_LAUNCH_CHECK();
     s->preview_iter = iter;
-    // the next camera pass (lane 2) adds into the planes this kernel reads: it waits for the preview by an event
+    // the next camera pass adds into the planes this kernel reads: its launch waits for the preview (camera_trace_launch)
     TK_HIP(hipEventRecord(s->ev_preview, ctx->stream));
-    TK_HIP(hipStreamWaitEvent(s->lane[2].stream, s->ev_preview, 0));
+    s->preview_pending = true;
     return TKHIP_OK;
 }
 
@@ -1952,10 +1952,9 @@ int tkhip_sppm_export_exchange(tkhip_ctx* ctx, int32_t* device_buf, void* stream
         TK_HIP(hipMemcpyAsync(device_buf + L.pow[w], s->loc_pow[w].p, n * 12, hipMemcpyDeviceToDevice, stream));
         TK_HIP(hipMemcpyAsync(device_buf + L.dir[w], s->loc_dir[w].p, n * 2, hipMemcpyDeviceToDevice, stream));
     }
-    // the next photon pass overwrites the rank's arrays: its lanes wait for these copies, the host does not
+    // the next photon pass overwrites the rank's arrays: it waits for these copies first (photon_pass_begin)
     TK_HIP(hipEventRecord(s->ev_exchange, stream));
-    TK_HIP(hipStreamWaitEvent(s->lane[0].stream, s->ev_exchange, 0));
-    TK_HIP(hipStreamWaitEvent(s->lane[1].stream, s->ev_exchange, 0));
+    s->export_pending = true;
     return TKHIP_OK;
 }
 
@@ -1966,7 +1965,14 @@ int tkhip_sppm_import_exchange(tkhip_ctx* ctx, const int32_t* device_gathered, v
     TK_REQUIRE(s->world > 1, TKHIP_E_STATE, "tkhip_sppm_import_exchange: a single rank installs its photons in tkhip_sppm_photon_pass");
     hipStream_t stream = static_cast<hipStream_t>(stream_handle);
     const ExchangeLayout L = exchange_layout(s);
-    TK_HIP(hipEventRecord(s->ev_exchange, stream));     // whatever filled the buffer on the caller's stream (the all-gather)
+    // Whatever filled the buffer on the caller's stream (the all-gather) has to be over before the maps' streams
+    // read it.  The host waits for that point of the caller's stream; it reads nothing and decides nothing there.
+    // (A device-side wait of the maps' streams on the event would spare the host even that, but waits between
+    // streams of different priority were seen to stall for good once a process holds more streams than the GPU
+    // has hardware queues.)
+    TK_HIP(hipEventRecord(s->ev_exchange, stream));
+    TK_HIP(hipEventSynchronize(s->ev_exchange));
+    s->export_pending = false;
     for (int w = 0; w < 2; ++w) {
         tkhip_map* m = s->map[w];
         const int64_t size = w == 0 ? s->prm.globalSize : s->prm.causticSize;
@@ -1976,7 +1982,6 @@ int tkhip_sppm_import_exchange(tkhip_ctx* ctx, const int32_t* device_gathered, v
         m->built = false;
         if (w == 1) s->stored_c = size;
         if (size == 0) { s->h_exchange[2 * w] = 0; s->h_exchange[2 * w + 1] = 0; continue; }
-        TK_HIP(hipStreamWaitEvent(m->stream, s->ev_exchange, 0));
         k_exchange_unpack<<<divup((int64_t)s->world * L.cap[w], 256), 256, 0, m->stream>>>(
             device_gathered, L.words, s->world, w, L.cap[w], L.pos[w], L.pow[w], L.dir[w], m->in_pos.as<float>(), m->in_pow.as<float>(),
             m->in_dir.as<uint16_t>(), m->cap, s->h_exchange);
