@@ -142,6 +142,7 @@ struct SppmState {
     int64_t n_slots = 0;
     Lane lane[3];
     int photon_loads = 5;            // see photon_launch_batch
+    int camera_share = 16;           // sixteenths of the wave slots the camera path kernel takes (steered with photon_loads)
     // world > 1: sixteenths of the GPU's wave slots the path kernel of each lane takes.  The three run side
     // by side from the start (whole grids of each would queue up behind one another) and one sixteenth
     // stays free for the small kernels between the passes; measured at rank 0 of 2: 4.55 -> 3.6 ms.
@@ -1352,7 +1353,8 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic, bo
 #endif
     if (s->counting) k_camera_first<true><<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
     else k_camera_first<false><<<divup(s->n_slots, kTraceBlock), kTraceBlock, 0, stream>>>(a, s->n_slots, counters);
-    const int waves = s->world > 1 ? std::max(s->path_waves[2] * s->share[2] / 16, 64) : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), s->path_waves[2]);
+    const int waves = s->world > 1 ? std::max(s->path_waves[2] * s->share[2] / 16, 64)
+                                   : (int)std::min<int64_t>(divup(s->n_slots, kPathBlock), std::max(s->path_waves[2] * s->camera_share / 16, 64));
     if (s->counting) k_camera_paths<true><<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
     else k_camera_paths<false><<<waves, kPathBlock, 0, stream>>>(a, s->world > 1 ? 1 : 0, counters);
     TK_LAUNCH_CHECK();
@@ -2155,11 +2157,19 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         const double photon_done = std::max(t_photon_end[0] + build_ms[0], t_photon_end[1] + build_ms[1]) - t0;
         const double camera_done = t_cam - t0;
         // (not in the first two iterations, whose photon chains run late for reasons of their own)
+        // Once the light-path grids are as large as they get (photon_loads 1: renders with millions of photons,
+        // whose light paths are the longer chain whatever their grids), the camera path kernel gives up wave
+        // slots instead, a sixteenth at a time, down to three sixteenths.
         if (iter < 2) {}
-        else if (photon_done > 1.05 * camera_done) s->photon_loads = std::max(1, s->photon_loads - 1);
-        else if (photon_done < 0.95 * camera_done) s->photon_loads = std::min(8, s->photon_loads + 1);
+        else if (photon_done > 1.05 * camera_done) {
+            if (s->photon_loads > 1) --s->photon_loads;
+            else s->camera_share = std::max(3, s->camera_share - 1);
+        } else if (photon_done < 0.95 * camera_done) {
+            if (s->camera_share < 16) ++s->camera_share;
+            else s->photon_loads = std::min(8, s->photon_loads + 1);
+        }
         static const bool verbose = getenv("TKHIP_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "tkhip: iteration %d: maps ready %.2f ms, queries ready %.2f ms -> photon_loads %d\n", iter, photon_done, camera_done, s->photon_loads);
+        if (verbose) fprintf(stderr, "tkhip: iteration %d: maps ready %.2f ms, queries ready %.2f ms -> photon_loads %d, camera share %d/16\n", iter, photon_done, camera_done, s->photon_loads, s->camera_share);
     }
     if (rc_g != TKHIP_OK) return rc_g;
     if (rc_c != TKHIP_OK) return rc_c;
