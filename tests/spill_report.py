@@ -21,10 +21,15 @@ WANT = ("k_camera_paths", "k_photon_paths", "k_camera_first", "k_photon_first")
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        res = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "--save-temps=obj", "-c",
-                              "-o", os.path.join(tmp, "o.o"), SRC], capture_output=True, text=True, cwd=tmp)
+        # two compilations: the resource remarks are not printed when the temporaries are kept
+        res = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c",
+                              "-o", os.path.join(tmp, "r.o"), SRC], capture_output=True, text=True, cwd=tmp)
         if res.returncode != 0:
             sys.exit(res.stderr[-2000:])
+        res2 = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["--save-temps=obj", "-c", "-o", os.path.join(tmp, "o.o"), SRC],
+                              capture_output=True, text=True, cwd=tmp)
+        if res2.returncode != 0:
+            sys.exit(res2.stderr[-2000:])
         asm = open([os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]).read()
     print("hipcc " + " ".join(f for f in FLAGS if not f.startswith("-I")) + "  (pathtracer_amd/csrc/sppm_render.hip)\n")
     print("%-46s %5s %6s %6s %8s %6s %5s" % ("kernel", "VGPR", "vspill", "sspill", "scratch", "LDS", "occ"))
