@@ -147,14 +147,30 @@ TKD bool tri_hit(const TriIsect& T, F3 o, F3 d, double tmax, double* tout, doubl
 
 // Slab test with the tMax padding of src/Bounds3.hpp:108-118; returns the
 // entry distance.  For a direction without zero components (finite inverses)
-// this min / max form decides exactly as the CPU code does.
-TKD bool box_hit(const float* bmin, const float* bmax, F3 o, F3 dinv, float tmax, float* tnear) {
+// this min / max form decides exactly as the CPU code does: each bound goes
+// through (bound - origin) * inverse, two roundings, as it does there.
+//
+// The arithmetic runs on pairs of floats: the six bounds of a box lie in memory
+// as (min.x min.y) (min.z max.x) (max.y max.z), so with the ray's origin and
+// inverse direction held as the pairs (x y) (z x) (y z) each subtraction and
+// each product serves two bounds with the same two roundings per component.
+typedef float F2 __attribute__((ext_vector_type(2)));
+struct RayPairs {
+    F2 o_xy, o_zx, o_yz, i_xy, i_zx, i_yz;
+};
+TKD RayPairs ray_pairs(F3 o, F3 dinv) {
+    RayPairs r;
+    r.o_xy = F2{o.x, o.y}; r.o_zx = F2{o.z, o.x}; r.o_yz = F2{o.y, o.z};
+    r.i_xy = F2{dinv.x, dinv.y}; r.i_zx = F2{dinv.z, dinv.x}; r.i_yz = F2{dinv.y, dinv.z};
+    return r;
+}
+TKD bool box_hit_pairs(F2 p0, F2 p1, F2 p2, const RayPairs& r, float tmax, float* tnear) {
     const float pad = 1 + 2 * gamma_n(3);
-    float tx0 = (bmin[0] - o.x) * dinv.x, tx1 = (bmax[0] - o.x) * dinv.x;
-    float ty0 = (bmin[1] - o.y) * dinv.y, ty1 = (bmax[1] - o.y) * dinv.y;
-    float tz0 = (bmin[2] - o.z) * dinv.z, tz1 = (bmax[2] - o.z) * dinv.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * pad;
+    const F2 a = (p0 - r.o_xy) * r.i_xy;      // tx0 ty0
+    const F2 b = (p1 - r.o_zx) * r.i_zx;      // tz0 tx1
+    const F2 c = (p2 - r.o_yz) * r.i_yz;      // ty1 tz1
+    float tn = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fminf(b.x, c.y));
+    float tf = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fmaxf(b.x, c.y)) * pad;
     *tnear = tn;
     return tn <= tf && tf > 0 && tn < tmax;
 }
@@ -262,6 +278,7 @@ TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
 // step; the votes below count those lanes only.
 template <bool COUNT, class STACK>
 TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest, WalkCount* wc) {
+    const RayPairs rp = ray_pairs(o, w.dinv);
     while (true) {
         const int busy = __popcll(__ballot(w.cur != kWalkOver));
         while (true) {
@@ -277,8 +294,10 @@ TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STA
                 hl = box_hit_zero_dir(nd.lmin, nd.lmax, o, d, w.dinv, w.tcull, &tl);
                 hr = box_hit_zero_dir(nd.rmin, nd.rmax, o, d, w.dinv, w.tcull, &tr);
             } else {
-                hl = box_hit(nd.lmin, nd.lmax, o, w.dinv, w.tcull, &tl);
-                hr = box_hit(nd.rmin, nd.rmax, o, w.dinv, w.tcull, &tr);
+                hl = box_hit_pairs(F2{nd.lmin[0], nd.lmin[1]}, F2{nd.lmin[2], nd.lmax[0]}, F2{nd.lmax[1], nd.lmax[2]}, rp,
+                                   w.tcull, &tl);
+                hr = box_hit_pairs(F2{nd.rmin[0], nd.rmin[1]}, F2{nd.rmin[2], nd.rmax[0]}, F2{nd.rmax[1], nd.rmax[2]}, rp,
+                                   w.tcull, &tr);
             }
             if (hl && hr) {
                 const bool right_first = tr < tl;
@@ -364,6 +383,7 @@ TKD Hit walk_wide_t(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_i
         const bool any_hit = __shfl(any_hit_in ? 1 : 0, owner) != 0;
         const F3 dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const bool zero_dir = isinf(dinv.x) || isinf(dinv.y) || isinf(dinv.z);
+        const RayPairs rp = ray_pairs(o, dinv);
         float tcull = tmax >= 3.0e38 ? 3.4e38f : (float)tmax * 1.0000002f;
         Hit best;
         best.prim = -1; best.t = tmax; best.u = 0; best.v = 0;
@@ -375,7 +395,8 @@ TKD Hit walk_wide_t(const DScene& sc, bool want, F3 o_in, F3 d_in, double tmax_i
                 float tn = 0.f;
                 bool hit = false;
                 if (ch.ref != kWideEmpty)
-                    hit = zero_dir ? box_hit_zero_dir(ch.lo, ch.hi, o, d, dinv, tcull, &tn) : box_hit(ch.lo, ch.hi, o, dinv, tcull, &tn);
+                    hit = zero_dir ? box_hit_zero_dir(ch.lo, ch.hi, o, d, dinv, tcull, &tn)
+                                   : box_hit_pairs(F2{ch.lo[0], ch.lo[1]}, F2{ch.lo[2], ch.hi[0]}, F2{ch.hi[1], ch.hi[2]}, rp, tcull, &tn);
                 Hit mine = best;
                 mine.prim = -1;
                 if (hit && ch.ref < 0) leaf_test(sc, ~ch.ref, o, d, &mine, COUNT ? &wc->prims : nullptr);

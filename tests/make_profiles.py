@@ -3,7 +3,7 @@ command list printed with --help) into the summaries kept under profiles/.  A he
 
     python3 tests/make_profiles.py <session dir> <round tag, e.g. r1>
 
-The session directory holds: r1_bench.json, r1_bench_steps20_warmup5.json, r1_bench_under_rocprof.json (bench lines),
+The session directory holds: line_bench.json, line_bench_steps20_warmup5.json, line_bench_under_rocprof.json (bench lines),
 kt/ (rocprofv3 --kernel-trace --stats), sq/ (--pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD
 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU), fs/ (--pmc FETCH_SIZE), ws/ (--pmc WRITE_SIZE), every pass
 a run of `python3 bench.py --no-cpu-baseline` of its own."""
@@ -31,7 +31,7 @@ def main(src, tag):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     for name in ("bench.json", "bench_steps20_warmup5.json", "bench_under_rocprof.json"):
-        line = [l for l in open(os.path.join(src, "r1_" + name)) if l.startswith("{")][-1]
+        line = [l for l in open(os.path.join(src, "line_" + name)) if l.startswith("{")][-1]
         with open(os.path.join(out, "%s_%s" % (tag, name)), "w") as f:
             f.write(json.dumps(json.loads(line), indent=1) + "\n")
     shutil.copy(glob.glob(os.path.join(src, "kt", "*kernel_stats.csv"))[0], os.path.join(out, tag + "_bench_kernel_stats.csv"))
@@ -57,13 +57,20 @@ def main(src, tag):
                 f.write("   %-60s dispatches %4d  total %.4g  per dispatch %.4g\n" % (k[:60], disp[k], c[name], c[name] / disp[k]))
                 if "k_gather_group" in k:
                     per[name] = c[name] / disp[k]
+                if "k_camera_paths<false>" in k:
+                    per["camera_" + name] = c[name] / disp[k]
     fetch, write = per["FETCH_SIZE"], per["WRITE_SIZE"]
+    cam_fetch, cam_write = per.get("camera_FETCH_SIZE", 0.0), per.get("camera_WRITE_SIZE", 0.0)
     with open(os.path.join(out, "hbm_traffic.json"), "w") as f:
         json.dump({"kernel": "k_gather_group", "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
                    "bytes_per_launch": (2.0 * fetch + write) * 1024.0,
-                   "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, averaged over the launches of "
-                           "both maps; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 "
-                           "bytes); uncorrected: %d bytes" % int((fetch + write) * 1024.0)}, f, indent=1)
+                   "k_camera_paths_fetch_size_kb_per_launch": cam_fetch, "k_camera_paths_write_size_kb_per_launch": cam_write,
+                   "k_camera_paths_bytes_per_launch": (2.0 * cam_fetch + cam_write) * 1024.0,
+                   "collected": tag,
+                   "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, averaged over the launches "
+                           "(one launch per iteration takes the groups of both maps); FETCH_SIZE doubled (gfx950 tallies the "
+                           "128-byte requests of wide coalesced reads at 64 bytes); uncorrected: %d bytes"
+                           % int((fetch + write) * 1024.0)}, f, indent=1)
 
 
 if __name__ == "__main__":
