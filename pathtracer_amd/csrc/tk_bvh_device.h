@@ -276,29 +276,18 @@ TKD void walk_begin(RayWalk& w, const DScene& sc, F3 d, double tmax) {
 // Advances the rays in flight (lanes with cur != kWalkOver) until at most
 // `rest` of them are unfinished.  Called by all the lanes that take part, in
 // step; the votes below count those lanes only.
+// The whole walk of a ray with an infinite inverse (a zero direction component), lane by lane with the exact
+// slab test.  Such rays are rare (axis-parallel mirror chains), so they are walked to the end where they are met
+// and the loops of walk_rays_t carry one slab test only.
 template <bool COUNT, class STACK>
-TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest, WalkCount* wc) {
-    const RayPairs rp = ray_pairs(o, w.dinv);
-    while (true) {
-        const int busy = __popcll(__ballot(w.cur != kWalkOver));
-        while (true) {
-            const bool inner = (unsigned)w.cur < (unsigned)kWalkOver;
-            const int n_inner = __popcll(__ballot(inner));
-            if (n_inner == 0 || (busy - n_inner) * 16 >= busy * kLeafShare) break;
-            if (!inner) continue;
+TKD void walk_zero_dir(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, WalkCount* wc) {
+    while (w.cur != kWalkOver) {
+        if (w.cur >= 0) {
             const BvhNode nd = sc.nodes[w.cur];
             if (COUNT) ++wc->nodes;
             float tl, tr;
-            bool hl, hr;
-            if (__builtin_expect(w.zero_dir, 0)) {
-                hl = box_hit_zero_dir(nd.lmin, nd.lmax, o, d, w.dinv, w.tcull, &tl);
-                hr = box_hit_zero_dir(nd.rmin, nd.rmax, o, d, w.dinv, w.tcull, &tr);
-            } else {
-                hl = box_hit_pairs(F2{nd.lmin[0], nd.lmin[1]}, F2{nd.lmin[2], nd.lmax[0]}, F2{nd.lmax[1], nd.lmax[2]}, rp,
-                                   w.tcull, &tl);
-                hr = box_hit_pairs(F2{nd.rmin[0], nd.rmin[1]}, F2{nd.rmin[2], nd.rmax[0]}, F2{nd.rmax[1], nd.rmax[2]}, rp,
-                                   w.tcull, &tr);
-            }
+            const bool hl = box_hit_zero_dir(nd.lmin, nd.lmax, o, d, w.dinv, w.tcull, &tl);
+            const bool hr = box_hit_zero_dir(nd.rmin, nd.rmax, o, d, w.dinv, w.tcull, &tr);
             if (hl && hr) {
                 const bool right_first = tr < tl;
                 st.push(w.sp, right_first ? nd.left : nd.right);
@@ -314,6 +303,48 @@ TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STA
             } else {
                 w.cur = kWalkOver;
             }
+        } else {
+            leaf_test(sc, ~w.cur, o, d, &w.h, COUNT ? &wc->prims : nullptr);
+            w.tcull = w.h.t >= 3.0e38 ? 3.4e38f : (float)w.h.t * 1.0000002f;
+            if ((any_hit && w.h.prim >= 0) || w.sp == 0) w.cur = kWalkOver;
+            else { --w.sp; w.cur = st.pop(w.sp); }
+        }
+    }
+}
+template <bool COUNT, class STACK>
+TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STACK st, int rest, WalkCount* wc) {
+    if (__builtin_expect(w.zero_dir && w.cur != kWalkOver, 0)) walk_zero_dir<COUNT>(sc, w, o, d, any_hit, st, wc);
+    const RayPairs rp = ray_pairs(o, w.dinv);
+    while (true) {
+        const int busy = __popcll(__ballot(w.cur != kWalkOver));
+        // (the votes make the loop condition the same for the whole wave: a scalar branch)
+        bool inner = (unsigned)w.cur < (unsigned)kWalkOver;
+        int n_inner = __popcll(__ballot(inner));
+        while (n_inner != 0 && (busy - n_inner) * 16 < busy * kLeafShare) {
+            if (inner) {
+                const BvhNode nd = sc.nodes[w.cur];
+                if (COUNT) ++wc->nodes;
+                float tl, tr;
+                const bool hl = box_hit_pairs(F2{nd.lmin[0], nd.lmin[1]}, F2{nd.lmin[2], nd.lmax[0]}, F2{nd.lmax[1], nd.lmax[2]}, rp, w.tcull, &tl);
+                const bool hr = box_hit_pairs(F2{nd.rmin[0], nd.rmin[1]}, F2{nd.rmin[2], nd.rmax[0]}, F2{nd.rmax[1], nd.rmax[2]}, rp, w.tcull, &tr);
+                if (hl && hr) {
+                    const bool right_first = tr < tl;
+                    st.push(w.sp, right_first ? nd.left : nd.right);
+                    ++w.sp;
+                    w.cur = right_first ? nd.right : nd.left;
+                } else if (hl) {
+                    w.cur = nd.left;
+                } else if (hr) {
+                    w.cur = nd.right;
+                } else if (w.sp > 0) {
+                    --w.sp;
+                    w.cur = st.pop(w.sp);
+                } else {
+                    w.cur = kWalkOver;
+                }
+            }
+            inner = (unsigned)w.cur < (unsigned)kWalkOver;
+            n_inner = __popcll(__ballot(inner));
         }
         if (w.cur < 0) {
             leaf_test(sc, ~w.cur, o, d, &w.h, COUNT ? &wc->prims : nullptr);
