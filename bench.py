@@ -429,7 +429,7 @@ def run_ranks(args):
     for it in range(args.warmup, args.warmup + args.steps):
         # several ranks, --ahead 1 / 2: the light paths (and the camera paths) of the next step are begun under
         # this step's gathers (not after the last one: nothing of step K+1 is left in flight)
-        D.iteration(backend, it, world, begin_next=args.ahead if world > 1 and it < last else 0)
+        D.iteration(backend, it, world, begin_next=args.ahead if it < last else 0)
     sync()
     elapsed = time.perf_counter() - t0
     gt = totals_of(lib, ctx_h, True)

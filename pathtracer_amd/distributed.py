@@ -247,7 +247,7 @@ def iteration(backend, it, world, stats=None, begin_next=False):
     depend on nothing this iteration still computes) and run under its tree builds and gathers; 2: its camera
     paths are started as well, before this iteration's gathers (their queries take the pixels' radii again
     when they are gathered).  The next call must then be for it + 1."""
-    if world == 1 and hasattr(backend, "iteration_single"):
+    if world == 1 and hasattr(backend, "iteration_single") and not begin_next and getattr(backend, "_lights_begun", None) != it:
         backend.iteration_single(it, stats)
         return [None, None]
     ahead = int(begin_next) if hasattr(backend, "camera_begin") else 0
