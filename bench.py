@@ -94,8 +94,22 @@ def cpu_baseline(scene, width, height, param, max_depth, rr, seed, threads):
     for name in ("tc_photon", "tc_camera"):
         rays_, nodes_, prims_ = fair[name]
         per_ray[name] = {"rays": rays_, "box_tests_per_ray": nodes_ / max(rays_, 1), "prim_tests_per_ray": prims_ / max(rays_, 1)}
+    # how the port's reference-faithful mode compares with the reference binary itself (measured where the
+    # reference builds, oracle/calibrate_cpu_baseline.py; the reference cannot run on the GPU box)
+    calibration = None
+    cp = os.path.join(ROOT, "profiles", "cpu_baseline_calibration.json")
+    if os.path.exists(cp):
+        with open(cp) as f:
+            cj = json.load(f)
+        ratio = float(cj["faithful_over_reference"])
+        calibration = {"port_seconds_over_reference_seconds": ratio,
+                       "value_reference_estimate": ratio / ref["sec_iter"],
+                       "note": "the port takes this share of the reference binary's time per iteration (same scene, size, photons, "
+                               "threads; profiles/cpu_baseline_calibration.json): the reference itself would run at about "
+                               "value_reference_estimate iterations/s here"}
     return {
         "value": 1.0 / ref["sec_iter"], "unit": "iterations/s", "cores": threads, "kind": "port", "iteration": 0,
+        "reference_calibration": calibration,
         "per_ray": per_ray,
         "sample": ("CPU oracle, iteration 0 of the same workload (the GPU's figure for the same iteration is iter0_ms), reference-faithful mode (z-only KD splits, far-first "
                    "BVH without t_max culling, per-call Mersenne-Twister seeding): " + describe(ref)),

@@ -143,6 +143,7 @@ struct SppmState {
     Lane lane[3];
     int photon_loads = 5;            // see photon_launch_batch
     int camera_share = 16;           // sixteenths of the wave slots the camera path kernel takes (steered with photon_loads)
+    bool steer_settled = false;   // the two chains have ended within 5 % of each other once
     // world > 1: sixteenths of the GPU's wave slots the path kernel of each lane takes.  The three run side
     // by side from the start (whole grids of each would queue up behind one another) and one sixteenth
     // stays free for the small kernels between the passes; measured at rank 0 of 2: 4.55 -> 3.6 ms.
@@ -2160,13 +2161,24 @@ int tkhip_sppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
         // Once the light-path grids are as large as they get (photon_loads 1: renders with millions of photons,
         // whose light paths are the longer chain whatever their grids), the camera path kernel gives up wave
         // slots instead, a sixteenth at a time, down to three sixteenths.
+        // The further apart the two are, the larger the step (two from 10 % on, three from 18 %), so that a
+        // render of the usual sixteen iterations spends most of them near the balance: one step moves either
+        // chain by a per cent or two.
+        const double ratio = photon_done / std::max(camera_done, 1e-3);
+        const bool balanced = ratio <= 1.05 && ratio >= 0.95;
+        if (iter >= 2 && balanced) s->steer_settled = true;   // from here on single steps: one late iteration must not undo the balance
+        const int step = s->steer_settled ? 1 : (ratio > 1.18 || ratio < 1.0 / 1.18) ? 3 : ((ratio > 1.10 || ratio < 1.0 / 1.10) ? 2 : 1);
         if (iter < 2) {}
         else if (photon_done > 1.05 * camera_done) {
-            if (s->photon_loads > 1) --s->photon_loads;
-            else s->camera_share = std::max(3, s->camera_share - 1);
+            for (int i = 0; i < step; ++i) {
+                if (s->photon_loads > 1) --s->photon_loads;
+                else s->camera_share = std::max(3, s->camera_share - 1);
+            }
         } else if (photon_done < 0.95 * camera_done) {
-            if (s->camera_share < 16) ++s->camera_share;
-            else s->photon_loads = std::min(8, s->photon_loads + 1);
+            for (int i = 0; i < step; ++i) {
+                if (s->camera_share < 16) ++s->camera_share;
+                else s->photon_loads = std::min(8, s->photon_loads + 1);
+            }
         }
         static const bool verbose = getenv("TKHIP_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "tkhip: iteration %d: maps ready %.2f ms, queries ready %.2f ms -> photon_loads %d, camera share %d/16\n", iter, photon_done, camera_done, s->photon_loads, s->camera_share);
