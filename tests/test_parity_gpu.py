@@ -37,6 +37,31 @@ def test_radical_inverse_matches_golden_and_oracle(gpu_ctx):
     assert (gpu_ctx.radical_inverse(dim, idx) == o).all()
 
 
+def test_radical_inverse_at_the_edges_of_its_digit_groups(gpu_ctx):
+    """Bases 3, 5, 7 and 11 take several digits at a time from a table: indices around every power of the base
+    (where the number of digits changes), around the powers of the table sizes, around 2^32 (where the index
+    leaves 32-bit arithmetic) and far beyond must give the digit loop's float."""
+    cases = []
+    for dim, base in ((1, 3), (2, 5), (3, 7), (4, 11)):
+        p = 1
+        while p < (1 << 63):
+            for v in (p - 2, p - 1, p, p + 1, 2 * p - 1, 2 * p, p * (base - 1), p * base - 1):
+                if 0 <= v < (1 << 64):
+                    cases.append((dim, v))
+            p *= base
+        for v in list(range(0, 300)) + [(1 << 32) + d for d in range(-3, 4)] + [(1 << 64) - 1, (1 << 63) + 12345, 10 ** 18 + 7]:
+            cases.append((dim, v))
+    rng = np.random.default_rng(5)
+    for dim in (1, 2, 3, 4):
+        for bits in (20, 31, 33, 40, 52, 64):
+            cases += [(dim, int(v)) for v in rng.integers(0, (1 << bits) - 1, 400, dtype=np.uint64, endpoint=True)]
+    dim = np.array([c[0] for c in cases], np.int32)
+    idx = np.array([c[1] for c in cases], np.uint64)
+    o = np.array([L.orc_radical_inverse(int(d), int(i)) for d, i in zip(dim, idx)], np.float32)
+    g = gpu_ctx.radical_inverse(dim, idx)
+    assert (g == o).all(), [(int(d), int(i)) for d, i in zip(dim[g != o][:5], idx[g != o][:5])]
+
+
 def test_pixel_update_bit_exact(gpu_ctx):
     g = golden("pixel_update.npz")
     f, p, r = gpu_ctx.pixel_update(g["flux"], g["photons"], g["radius2"], g["lindir"], g["found"], g["r2ret"])
