@@ -37,10 +37,9 @@ def test_radical_inverse_matches_golden_and_oracle(gpu_ctx):
     assert (gpu_ctx.radical_inverse(dim, idx) == o).all()
 
 
-def test_radical_inverse_at_the_edges_of_its_digit_groups(gpu_ctx):
-    """Bases 3, 5, 7 and 11 take several digits at a time from a table: indices around every power of the base
-    (where the number of digits changes), around the powers of the table sizes, around 2^32 (where the index
-    leaves 32-bit arithmetic) and far beyond must give the digit loop's float."""
+def test_radical_inverse_at_the_edges_of_its_digit_counts(gpu_ctx):
+    """Indices around every power of the base (where the number of digits changes), around 2^32 (where the index
+    leaves 32-bit arithmetic) and far beyond give the float of the oracle's digit loop."""
     cases = []
     for dim, base in ((1, 3), (2, 5), (3, 7), (4, 11)):
         p = 1

@@ -6,7 +6,8 @@ Upstream draws its Russian-roulette numbers and the triangle pick of a light sam
 (the patch is recorded in each fixture, key *_patch), and the numbers fed are the ones the oracle and the HIP
 kernels draw at the same places (oracle_py.photon_draws / pt_draws): upstream's tracePhoton(H) then traces the
 path the oracle traces for Halton index H, and the stored photons can be compared one by one.  What is left
-between the two is the last bit of the float trigonometry, which moves a few per cent of the
+between the two is the last bit of the float trigonometry (upstream calls libm's float cos / sin, the oracle and
+the kernels round the double function to float so that host and GPU agree), which moves a few per cent of the
 positions by an ulp or so: counts and direction bytes are equal, positions and powers close.
 """
 import os
