@@ -21,11 +21,14 @@ ls "$out" "$out/kt" | head -40
 exit 0
 fi
 # the other configurations and the per-rank shares of an 8-GPU job, one bench line each
-timeout -k 10 200 python3 bench.py --size 512 --no-cpu-baseline > "$out/cfg_dragon_512.json" 2>> "$out/bench.err"
-timeout -k 10 200 python3 bench.py --scene cornell_box.scene --size 512 --no-cpu-baseline > "$out/cfg_box_512.json" 2>> "$out/bench.err"
-timeout -k 10 200 python3 bench.py --scene cornell_sphere.scene --size 512 --no-cpu-baseline > "$out/cfg_sphere_512.json" 2>> "$out/bench.err"
-timeout -k 10 200 python3 bench.py --scene cornell_sphere.scene --size 1024 --no-cpu-baseline > "$out/cfg_sphere_1024.json" 2>> "$out/bench.err"
-timeout -k 10 200 python3 bench.py --tree median --no-cpu-baseline > "$out/cfg_tree_median.json" 2>> "$out/bench.err"
-timeout -k 10 300 python3 bench.py --photons 2000000 500000 --no-cpu-baseline --jobs 0 > "$out/cfg_2m_500k.json" 2>> "$out/bench.err"
-timeout -k 10 400 python3 bench.py --synthetic 2236 --size 4096 --photons 16000000 4000000 --no-cpu-baseline --jobs 0 --steps 5 --warmup 3 > "$out/cfg_synthetic_field.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --size 512 --steps 20 --warmup 5 --jobs 10 --no-cpu-baseline > "$out/cfg_dragon_512.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --scene cornell_box.scene --size 512 --steps 20 --warmup 5 --jobs 10 --no-cpu-baseline > "$out/cfg_box_512.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --scene cornell_sphere.scene --size 512 --steps 20 --warmup 5 --jobs 10 --no-cpu-baseline > "$out/cfg_sphere_512.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --scene cornell_sphere.scene --size 1024 --steps 20 --warmup 5 --jobs 10 --no-cpu-baseline > "$out/cfg_sphere_1024.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --tree median --steps 20 --warmup 5 --jobs 10 --no-cpu-baseline > "$out/cfg_tree_median.json" 2>> "$out/bench.err"
+timeout -k 10 300 python3 bench.py --photons 2000000 500000 --steps 20 --warmup 5 --no-cpu-baseline --jobs 10 > "$out/cfg_2m_500k.json" 2>> "$out/bench.err"
+timeout -k 10 400 python3 bench.py --synthetic 2236 --size 4096 --photons 16000000 4000000 --no-cpu-baseline --jobs 0 --steps 8 --warmup 5 > "$out/cfg_synthetic_field.json" 2>> "$out/bench.err"
+# two ranks sharing the one GPU (gloo moves the exchange through host memory): the launcher and ranks_seen
+timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --no-cpu-baseline --jobs 0 > "$out/cfg_two_ranks_gloo.json" 2>> "$out/bench.err"
+timeout -k 10 300 python3 bench.py --gpus 2 --driver group --share-gpus --no-cpu-baseline --jobs 0 > "$out/cfg_two_ranks_group.json" 2>> "$out/bench.err"
 ls "$out" | head -40
