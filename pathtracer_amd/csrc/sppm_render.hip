@@ -45,7 +45,8 @@ namespace tkd {
 // 4 % of the iteration.  Everything before kCounterBatchInts is cleared for
 // every batch of a pass; the 64-bit totals behind it run over the whole pass.
 enum { C_QA = 0 /* work cursor of the path kernels */, C_QB = 32, C_QD = 64, C_NGQ = 96, C_NCQ = 128, C_TOTAL = 160, C_USED = 161,
-       C_RAYS = 192 /* u64 */, C_NODES = 194 /* u64 */, C_PRIMS = 196 /* u64 */ };   // the last two: counting instances only
+       C_RAYS = 192 /* u64 */, C_NODES = 194 /* u64 */, C_PRIMS = 196 /* u64 */,   // the last two: counting instances only
+       C_WALK_SECTIONS = 198 /* 4 x u64: node_turns, node_busy, leaf_turns, leaf_lanes of the counting instances */ };
 constexpr int kCounterBatchInts = 192;
 constexpr int kCounterBytes = 256 * 4;
 
@@ -482,9 +483,14 @@ TKD void count_wave_rays(int32_t* counters, int nrays) {
 TKD void count_wave_walk(int32_t* counters, const WalkCount& wc) {
     int n = wc.nodes, p = wc.prims;
     for (int o2 = 32; o2 > 0; o2 >>= 1) { n += __shfl_xor(n, o2); p += __shfl_xor(p, o2); }
+    int sec[4] = {wc.node_turns, wc.node_busy, wc.leaf_turns, wc.leaf_lanes};
+    for (int k = 0; k < 4; ++k)
+        for (int o2 = 32; o2 > 0; o2 >>= 1) sec[k] += __shfl_xor(sec[k], o2);
     if ((threadIdx.x & 63) == 0) {
         if (n > 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_NODES]), (unsigned long long)n);
         if (p > 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_PRIMS]), (unsigned long long)p);
+        for (int k = 0; k < 4; ++k)
+            if (sec[k] > 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[C_WALK_SECTIONS + 2 * k]), (unsigned long long)sec[k]);
     }
 }
 
@@ -498,7 +504,7 @@ template <int KIND, bool COUNT = false>
 __global__ void __launch_bounds__(kTraceBlock) k_photon_first(PhotonArgs a, int64_t B, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kTraceBlock];
     LdsStack stk{&s_stack[threadIdx.x]};
-    WalkCount wc{0, 0};
+    WalkCount wc{};
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     bool alive = false, specular = false;
     int traced = 0;
@@ -544,7 +550,7 @@ template <int KIND, bool COUNT = false>
 __global__ void __launch_bounds__(kPathBlock, 4) k_photon_paths(PhotonArgs a, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
-    WalkCount wc{0, 0};
+    WalkCount wc{};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     // A queue shorter than the grid is spread over all waves (lanes_in_use); the paths at its front (from
     // specular surfaces: the long ones) are then dealt thinly too, a few to every wave with the wave's
@@ -870,7 +876,7 @@ template <bool COUNT = false>
 __global__ void __launch_bounds__(kTraceBlock) k_camera_first(CameraArgs a, int64_t n_slots, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kTraceBlock];
     LdsStack stk{&s_stack[threadIdx.x]};
-    WalkCount wc{0, 0};
+    WalkCount wc{};
     const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     bool alive = slot < n_slots;
     int pixel = 0, x = 0, y = 0, bounce = 0, nrays = 0;
@@ -910,7 +916,7 @@ template <bool COUNT = false>
 __global__ void __launch_bounds__(kPathBlock, 4) k_camera_paths(CameraArgs a, int spread, int32_t* counters) {
     __shared__ int s_stack[kStackDepth * kPathBlock];
     LdsStackT<kPathBlock> stk{&s_stack[threadIdx.x]};
-    WalkCount wc{0, 0};
+    WalkCount wc{};
     const int n_front = counters[C_QB], n = n_front + counters[C_QD];
     if (!spread && (int64_t)blockIdx.x * 64 >= n) return;   // the waves before this one take the whole queue
     // spread: the paths at the front of the queue (from specular surfaces: the long ones) are dealt thinly
@@ -1162,13 +1168,18 @@ static double now_ms() {
 }
 
 // Rays, nodes fetched and primitives tested (C_RAYS, C_NODES, C_PRIMS: consecutive) of a lane's pass; cleared.
-static int read_walk_counters(Lane& l, int64_t out[3]) {
-    unsigned long long v[3] = {0, 0, 0};
+static int read_walk_counters(Lane& l, int64_t out[3], bool counting) {
+    unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
     int32_t* c = l.counters.as<int32_t>();
-    TK_HIP(hipMemcpyAsync(v, &c[C_RAYS], 24, hipMemcpyDeviceToHost, l.stream));
+    TK_HIP(hipMemcpyAsync(v, &c[C_RAYS], sizeof v, hipMemcpyDeviceToHost, l.stream));
     TK_HIP(hipStreamSynchronize(l.stream));
-    TK_HIP(hipMemsetAsync(&c[C_RAYS], 0, 24, l.stream));
+    TK_HIP(hipMemsetAsync(&c[C_RAYS], 0, sizeof v, l.stream));
     for (int i = 0; i < 3; ++i) out[i] = (int64_t)v[i];
+    static const bool verbose = getenv("TKHIP_VERBOSE") != nullptr;
+    if (verbose && counting && v[3] > 0)   // counting instances: what share of the lanes the sections of the walk keep busy
+        fprintf(stderr, "tkhip: walks of this lane's pass: node loop %.3g lane-turns, %.1f %% with a ray under way, %.1f %% visiting a node; "
+                "leaf phase %.3g lane-turns, %.1f %% testing a leaf\n", (double)v[3], 100.0 * v[4] / v[3], 100.0 * v[1] / v[3],
+                (double)v[5], v[5] ? 100.0 * v[6] / v[5] : 0.0);
     return TKHIP_OK;
 }
 
@@ -1252,7 +1263,7 @@ static int photon_pass_begin(tkhip_ctx* ctx, int64_t* B_out) {
         s->export_pending = false;
     }
     if (s->quota[KIND] <= 0) return TKHIP_OK;
-    TK_HIP(hipMemsetAsync(&ln.counters.as<int32_t>()[C_RAYS], 0, 24, ln.stream));
+    TK_HIP(hipMemsetAsync(&ln.counters.as<int32_t>()[C_RAYS], 0, 56, ln.stream));
     return photon_launch_batch<KIND>(ctx, 0, 0, B_out);
 }
 
@@ -1348,7 +1359,7 @@ static int camera_trace_launch(tkhip_ctx* ctx, int iter, bool expect_caustic, bo
     a.qcap = s->n_slots;
     a.q = PathQueue{ln.q_o.as<float4>(), ln.q_d.as<float4>(), ln.q_w.as<float4>(), (int)s->n_slots};
     TK_HIP(hipMemsetAsync(counters, 0, kCounterBatchInts * 4, stream));
-    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 24, stream));
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 56, stream));
 #ifdef TK_CP_STAMPS
     TK_HIP(hipMemsetAsync(&counters[224], 0, 64, stream));
 #endif
@@ -1504,7 +1515,7 @@ static int gather_both(tkhip_ctx* ctx, TkIterStats* st) {
 static int collect_rays(tkhip_ctx* ctx, int lane, TkIterStats* st) {
     if (!st) return TKHIP_OK;
     int64_t v[3] = {0, 0, 0};
-    TK_TRY(read_walk_counters(ctx->sppm->lane[lane], v));
+    TK_TRY(read_walk_counters(ctx->sppm->lane[lane], v, ctx->sppm->counting));
     st->rays += v[0];
     if (lane == 2) { st->rays_camera += v[0]; st->node_visits_camera += v[1]; st->prim_tests_camera += v[2]; }
     else { st->node_visits_light += v[1]; st->prim_tests_light += v[2]; }
@@ -2437,7 +2448,7 @@ int tkhip_hsppm_iteration(tkhip_ctx* ctx, int iter, TkIterStats* st) {
     Lane& ln = s->lane[0];
     const int64_t per_it = s->prm.globalSize;
     int32_t* counters = ln.counters.as<int32_t>();
-    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 24, ln.stream));
+    TK_HIP(hipMemsetAsync(&counters[C_RAYS], 0, 56, ln.stream));
     for (int64_t done = 0; done < per_it;) {
         const int64_t B = std::min<int64_t>(per_it - done, (int64_t)1 << 22);
         PhotonArgs a{};

@@ -251,8 +251,12 @@ constexpr int kWalkOver = 0x7fffffff;   // RayWalk::cur of a lane whose ray has 
 constexpr int kLeafShare = 8;           // sixteenths of the rays in flight that must hold a leaf before leaves are tested
 // What a counting instance of a walk adds up per lane: nodes of the tree fetched (a node holds the boxes of
 // both children; a node of the eight-children tree counts as four, by its size) and primitives tested.
+// node_turns / leaf_turns: turns of the inner-node loop and of the leaf phase this lane sat through, node_busy:
+// those of the node loop in which it still had a ray under way (walking or waiting with a leaf), leaf_lanes:
+// leaf phases in which it tested a leaf — what share of the lanes each section of the walk keeps busy.
 struct WalkCount {
     int nodes, prims;
+    int node_turns, node_busy, leaf_turns, leaf_lanes;
 };
 struct RayWalk {
     int cur;        // node to visit next, ~leaf to test next, or kWalkOver
@@ -321,6 +325,7 @@ TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STA
         bool inner = (unsigned)w.cur < (unsigned)kWalkOver;
         int n_inner = __popcll(__ballot(inner));
         while (n_inner != 0 && (busy - n_inner) * 16 < busy * kLeafShare) {
+            if (COUNT) { ++wc->node_turns; if (w.cur != kWalkOver) ++wc->node_busy; }
             if (inner) {
                 const BvhNode nd = sc.nodes[w.cur];
                 if (COUNT) ++wc->nodes;
@@ -346,7 +351,9 @@ TKD void walk_rays_t(const DScene& sc, RayWalk& w, F3 o, F3 d, bool any_hit, STA
             inner = (unsigned)w.cur < (unsigned)kWalkOver;
             n_inner = __popcll(__ballot(inner));
         }
+        if (COUNT && __any(w.cur < 0)) ++wc->leaf_turns;
         if (w.cur < 0) {
+            if (COUNT) ++wc->leaf_lanes;
             leaf_test(sc, ~w.cur, o, d, &w.h, COUNT ? &wc->prims : nullptr);
             w.tcull = w.h.t >= 3.0e38 ? 3.4e38f : (float)w.h.t * 1.0000002f;
             if ((any_hit && w.h.prim >= 0) || w.sp == 0) w.cur = kWalkOver;
