@@ -448,7 +448,10 @@ TKD bool photon_step(const PhotonArgs& a, int slot, int bounce, PhotonPath& P, b
 constexpr int kPathBlock = 64;   // one wave per block: the kernels below use wave-wide votes as barriers
 // The path kernels go on (walk_rays returns) once all but 1/8 of the rays a
 // wave has in flight have finished: measured best among 1/2 .. 1/32.
-constexpr int kWalkRestShift = 3;
+#ifndef TK_WALK_REST_SHIFT
+#define TK_WALK_REST_SHIFT 3            // (a build flag for sweeps)
+#endif
+constexpr int kWalkRestShift = TK_WALK_REST_SHIFT;
 
 // Hands the idle lanes of a wave the next unstarted work items: returns this
 // lane's item or -1.  *exhausted turns true (for the whole wave) once the

@@ -248,7 +248,10 @@ TKD void leaf_test(const DScene& sc, int enc, F3 o, F3 d, Hit* h, int* prims_tes
 // finished, those lanes go on with their paths (and start their next rays),
 // and the slow rays simply continue in the next call.
 constexpr int kWalkOver = 0x7fffffff;   // RayWalk::cur of a lane whose ray has finished (or that has none)
-constexpr int kLeafShare = 8;           // sixteenths of the rays in flight that must hold a leaf before leaves are tested
+#ifndef TK_LEAF_SHARE
+#define TK_LEAF_SHARE 8                 // (a build flag for sweeps)
+#endif
+constexpr int kLeafShare = TK_LEAF_SHARE;   // sixteenths of the rays in flight that must hold a leaf before leaves are tested
 // What a counting instance of a walk adds up per lane: nodes of the tree fetched (a node holds the boxes of
 // both children; a node of the eight-children tree counts as four, by its size) and primitives tested.
 // node_turns / leaf_turns: turns of the inner-node loop and of the leaf phase this lane sat through, node_busy:
